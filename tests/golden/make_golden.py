@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Needs /root/reference (absent on the GPU box: the fixtures are committed).  Only
+inputs/outputs are stored -- never reference source.  Visualization-only
+third-party imports of the reference (torchvision, torchmetrics, cv2) are
+replaced by inert stand-ins that raise if anything on the math path calls them
+(SURVEY.md App. A).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/code"
+sys.path.insert(0, ROOT)
+
+from oracle.unet_ref import random_params  # noqa: E402  (weight recipe shared with the tests)
+
+
+# --------------------------------------------------------------------------- #
+def _stub_modules():
+    class _Loud:
+        def __init__(self, name):
+            self._n = name
+
+        def __call__(self, *a, **k):
+            raise RuntimeError(f"stub {self._n} called on the math path")
+
+        def __getattr__(self, k):
+            return _Loud(self._n + "." + k)
+
+    def mod(name, attrs=()):
+        m = types.ModuleType(name)
+        for a in attrs:
+            setattr(m, a, _Loud(name + "." + a))
+        sys.modules[name] = m
+        return m
+
+    tv = mod("torchvision", ["transforms", "utils"])
+    tv.utils = mod("torchvision.utils", ["save_image", "make_grid"])
+    tv.transforms = mod("torchvision.transforms", ["Normalize", "Resize", "RandomHorizontalFlip",
+                                                   "RandomVerticalFlip", "Compose"])
+    tv.transforms.functional = mod("torchvision.transforms.functional", ["rotate"])
+    mod("torchmetrics"); mod("torchmetrics.image")
+    mod("torchmetrics.image.fid", ["FrechetInceptionDistance"])
+    mod("cv2")
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+def seed_all(s=0):
+    torch.manual_seed(s); np.random.seed(s); random.seed(s)      # main_train_masked.py:441-445
+
+
+def base_args(**kw):
+    """Defaults of main_train_masked.py:351-417 that the hot path reads."""
+    a = argparse.Namespace(
+        dir_dataset="synthetic", data_size=8, in_channel=3, out_channel=3, batch_size=4,
+        ddpm_num_steps=10, updated_ddpm_num_steps=10, ddpm_schedule="linear", ddpm_schedule_base=10.0,
+        scheduler_num_scale_timesteps=1, select_degrade_pixel="thresholding", degrade_channel="1-channel",
+        mean_option=0, mean_area="image-wise", shift_type="noise_with_perturbation", noise_mean=0.0,
+        sample_latent_shape="zero", sampling="momentum", momentum_adaptive="base_momentum",
+        adaptive_momentum_rate=0.9, sampling_mask_dependency="independent", sample_num=2,
+        loss_weight_use=False, loss_weight_power_base=10.0, use_ema=False, ema_inv_gamma=1.0, ema_power=0.75,
+        ema_max_decay=0.9999, weight_dtype=torch.float32, save_images_epochs=10, mixed_precision="no",
+        gradient_accumulation_steps=1)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+# --------------------------------------------------------------------------- #
+def gen_schedules(scheduler_mod, out):
+    for size in (32, 64):
+        for kind in ("linear", "log", "exponential"):
+            for T in (10, 50, 250, 1000):
+                a = base_args(data_size=size, ddpm_schedule=kind, ddpm_num_steps=T)
+                s = scheduler_mod.Scheduler(a)
+                steps = s.update_ddpm_num_steps(T)
+                key = f"sched_{kind}_{T}_{size}"
+                out[key + "_ratio"] = npy(s.get_ratio_list())
+                out[key + "_pixels"] = npy(s.get_black_area_num_pixels_all())
+                out[key + "_steps"] = np.array(steps)
+    # timestep subsets (scheduler.py:173-192)
+    for scale in (1, 3):
+        a = base_args(data_size=32, ddpm_schedule="linear", ddpm_num_steps=50, scheduler_num_scale_timesteps=scale)
+        s = scheduler_mod.Scheduler(a); s.update_ddpm_num_steps(50)
+        for epoch in (0, 3, 5, 8):
+            out[f"epochsteps_s{scale}_e{epoch}"] = np.array(s.get_timesteps_epoch(epoch, 9))
+    # gather + loss weights
+    a = base_args(data_size=32, ddpm_schedule="log", ddpm_num_steps=50, select_degrade_pixel="indexing")
+    s = scheduler_mod.Scheduler(a); steps = s.update_ddpm_num_steps(50)
+    t = torch.tensor([1, 2, steps // 2, steps])
+    out["gather_log_idx_t"] = npy(t)
+    out["gather_log_idx"] = npy(s.get_black_area_num_pixels_time(t))
+    a.select_degrade_pixel = "thresholding"
+    out["gather_log_thr"] = npy(s.get_black_area_num_pixels_time(t.float()))
+    out["lossw"] = npy(s.get_weight_timesteps(torch.tensor([0, 1, 7, steps - 1]), 10.0))
+
+
+def gen_degrade(scheduler_mod, out):
+    n, c, hw = 4, 3, 8
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.rand(n, c, hw, hw, generator=g) * 2 - 1
+    out["deg_x0"] = npy(x0)
+    combos = [
+        ("thresholding", "1-channel", "linear", 0, "image-wise"),
+        ("thresholding", "1-channel", "linear", 0.5, "image-wise"),
+        ("thresholding", "3-channel", "linear", 0, "image-wise"),
+        ("thresholding", "1-channel", "exponential", "degraded_area", "image-wise"),
+        ("thresholding", "1-channel", "exponential", "degraded_area", "channel-wise"),
+        ("thresholding", "3-channel", "log", "non_degraded_area", "channel-wise"),
+        ("thresholding", "1-channel", "log", "non_degraded_area", "image-wise"),
+        ("indexing", None, "log", 0, "image-wise"),
+        ("indexing", None, "log", "degraded_area", "channel-wise"),
+    ]
+    out["deg_ncombos"] = np.array(len(combos))
+    for i, (sel, ch, kind, mo, ma) in enumerate(combos):
+        a = base_args(data_size=hw, ddpm_schedule=kind, ddpm_num_steps=10, select_degrade_pixel=sel,
+                      degrade_channel=ch, mean_option=mo, mean_area=ma)
+        s = scheduler_mod.Scheduler(a); steps = s.update_ddpm_num_steps(10)
+        t = torch.tensor([2, steps // 2, steps - 1, steps])[:n]
+        seed_all(100 + i)
+        amount = s.get_black_area_num_pixels_time(t.float() if sel == "thresholding" else t)
+        r = s.degrade_training(amount, x0, mean_option=mo, mean_area=ma)
+        seed_all(200 + i)
+        r2 = s.degrade_independent_base_sampling(amount[:1].expand(n) if sel == "thresholding" else amount[:1].expand(n),
+                                                 x0, mean_option=mo, mean_area=ma)
+        r3 = s.degrade_with_mask(x0, r2[1], mo, ma)
+        out[f"deg{i}_cfg"] = np.array([str(sel), str(ch), kind, str(mo), ma])
+        out[f"deg{i}_t"] = npy(t)
+        for j, nm in enumerate(("img", "mask", "dmask", "mean")):
+            out[f"deg{i}_train_{nm}"] = npy(r[j])
+        for j, nm in enumerate(("img", "mask", "mean")):
+            out[f"deg{i}_samp_{nm}"] = npy(r2[j])
+        out[f"deg{i}_withmask"] = npy(r3)
+
+
+def gen_shift(scheduler_mod, out):
+    types_ = ["1-d_constant", "3-d_constant", "noise_reduction", "noise_std_reduction",
+              "noise_with_perturbation", "non_shift"]
+    for (n, hw, tag) in ((4, 8, "n4"), (8, 8, "nEQw")):        # second case: N == W (D10)
+        for i, st in enumerate(types_):
+            a = base_args(data_size=hw, ddpm_schedule="linear", ddpm_num_steps=10, shift_type=st, noise_mean=0.25)
+            s = scheduler_mod.Scheduler(a); s.update_ddpm_num_steps(10)
+            t = torch.tensor([(3 * k) % 10 + 1 for k in range(n)]).float()
+            seed_all(300 + i)
+            sh = s.get_schedule_shift_time(t, torch.zeros(n, 3, hw, hw))
+            out[f"shift_{tag}_{st}"] = npy(sh.contiguous())
+            out[f"shift_{tag}_{st}_t"] = npy(t)
+
+
+TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2], num_res_blocks=1,
+            apply_attn=[False, True])
+
+
+def build_ref_unet(unet6, cfg, seed=1234):
+    m = unet6.UNet(cfg["in_channels"], cfg["hid_channels"], cfg["out_channels"], cfg["ch_multipliers"],
+                   cfg["num_res_blocks"], cfg["apply_attn"])
+    p = random_params(cfg, seed)
+    assert list(m.state_dict().keys()) == list(p.keys()), "state_dict key grammar mismatch"
+    m.load_state_dict(p)
+    return m
+
+
+def gen_unet(unet6, out):
+    g = torch.Generator().manual_seed(5)
+    # pieces in isolation
+    t = torch.tensor([1.0, 7.0, 250.0, 1000.0])
+    out["temb_t"] = npy(t); out["temb_128"] = npy(unet6.get_timestep_embedding(t, 128))
+    x = torch.randn(2, 32, 8, 8, generator=g)
+    pad = unet6.SamePad2d(3, 2)(x)
+    out["samepad_x"] = npy(x); out["samepad_shape"] = np.array(pad.shape)
+    # full tiny model forward + backward
+    m = build_ref_unet(unet6, TINY)
+    x = (torch.rand(2, 3, 16, 16, generator=g) * 2 - 1).requires_grad_(True)
+    t = torch.tensor([3.0, 41.0])
+    y = m(x, t)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out["unet_x"] = npy(x); out["unet_t"] = npy(t); out["unet_y"] = npy(y); out["unet_gy"] = npy(gy)
+    out["unet_gx"] = npy(x.grad)
+    sd = dict(m.named_parameters())
+    for k in ("in_conv.weight", "out_conv.2.weight", "embed.0.weight", "middle.1.project_in.weight",
+              "downsamples.level_0.1.1.weight", "upsamples.level_1.2.1.weight", "upsamples.level_0.0.skip.weight",
+              "downsamples.level_1.0.0.fc.weight", "middle.0.norm1.weight", "middle.0.norm1.bias", "out_conv.2.bias"):
+        out["unet_grad::" + k] = npy(sd[k].grad)
+    # the named preset at 32x32 (Model('unet6',3,32,32,3)): forward only, N=1
+    from models import models_Unet
+    big = models_Unet.Model("unet6", 3, 32, 32, 3)
+    cfg = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
+               apply_attn=[False, False, True, False])
+    p = random_params(cfg, 77)
+    assert list(big.state_dict().keys()) == list(p.keys())
+    big.load_state_dict(p)
+    xb = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    tb = torch.tensor([500.0])
+    with torch.no_grad():
+        out["unet32_x"] = npy(xb); out["unet32_t"] = npy(tb); out["unet32_y"] = npy(big(xb, tb))
+    out["unet32_nparams"] = np.array(sum(v.numel() for v in big.parameters()))
+
+
+class _Wrap(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, x, t):
+        return types.SimpleNamespace(sample=self.net(x, t))
+
+
+def gen_sampler(scheduler_mod, sampler_mod, unet6, out):
+    i = 0
+    for dep in ("independent", "dependent_prev"):
+        for mode in ("base_momentum", "base_sampling"):
+            for sel, ch, kind, st in (("thresholding", "1-channel", "linear", "noise_with_perturbation"),
+                                      ("indexing", None, "log", "1-d_constant")):
+                a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=6, select_degrade_pixel=sel,
+                              degrade_channel=ch, shift_type=st, sampling_mask_dependency=dep,
+                              momentum_adaptive=mode, sample_num=2, sample_latent_shape="uniform")
+                s = scheduler_mod.Scheduler(a); steps = s.update_ddpm_num_steps(6)
+                ts = s.get_timesteps_epoch(0, 1)
+                smp = sampler_mod.Sampler(None, a, s, [None] * 3)
+                model = _Wrap(build_ref_unet(unet6, TINY)).eval()
+                seed_all(400 + i)
+                x0, hist = smp.sample(model, ts)
+                out[f"samp{i}_cfg"] = np.array([dep, mode, sel, str(ch), kind, st])
+                out[f"samp{i}_ts"] = np.array(ts)
+                out[f"samp{i}_x0"] = npy(x0)
+                out[f"samp{i}_hist"] = np.stack([npy(h) for h in hist])
+                i += 1
+    out["samp_n"] = np.array(i)
+
+
+def gen_train_step(scheduler_mod, unet6, out):
+    """One real `_run_batch` of each trainer with AdamW (main_train_masked.py:134-141)."""
+    import accelerate
+    import trainer_masked
+    import trainer_masked_mean_shift
+    tmp = tempfile.mkdtemp()
+    dirs = types.SimpleNamespace(list_dir={"train_loss": tmp, "checkpoint": tmp, "ema_sample_img": tmp})
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    out["step_x0"] = npy(x0)
+    watch = ["in_conv.weight", "out_conv.2.weight", "embed.2.bias", "middle.1.project_out.weight",
+             "upsamples.level_0.1.norm2.weight"]
+    for name, mod, st, sel, ch, kind, lw in (
+            ("ms", trainer_masked_mean_shift, "noise_with_perturbation", "thresholding", "1-channel", "linear", False),
+            ("ms_w", trainer_masked_mean_shift, "1-d_constant", "thresholding", "3-channel", "exponential", True),
+            ("base", trainer_masked, "non_shift", "indexing", None, "log", False)):
+        a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=10, select_degrade_pixel=sel, degrade_channel=ch,
+                      shift_type=st, loss_weight_use=lw, batch_size=4, sample_num=2, sample_latent_shape="zero")
+        model = _Wrap(build_ref_unet(unet6, TINY))
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        lr_s = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0)
+        acc = accelerate.Accelerator(cpu=True)
+        if name == "base":
+            class T(mod.Trainer):                      # constructor bypass
+                def __init__(self, args, model, opt, lr_s, acc):
+                    self.args, self.model, self.optimizer, self.lr_scheduler, self.accelerator = args, model, opt, lr_s, acc
+                    self.ema_model = None; self.lr_list = []; self.global_step = 0
+                    self.Scheduler = scheduler_mod.Scheduler(args)
+            tr = T(a, model, opt, lr_s, acc)
+        else:
+            tr = mod.Trainer(a, None, None, [None] * 3, model, None, opt, lr_s, acc)
+        steps = tr.Scheduler.update_ddpm_num_steps(a.ddpm_num_steps)
+        a.updated_ddpm_num_steps = steps
+        tr.timesteps_used_epoch = tr.Scheduler.get_timesteps_epoch(0, 1)
+        seed_all(500)
+        r = tr._run_batch(0, (x0, None, None), 0, 1, 0, dirs, None)
+        loss = r if isinstance(r, float) else r[0]
+        out[f"step_{name}_cfg"] = np.array([st, sel, str(ch), kind, str(lw)])
+        out[f"step_{name}_loss"] = np.array(loss, dtype=np.float64)
+        out[f"step_{name}_pred"] = npy(tr.mask)
+        out[f"step_{name}_xin"] = npy(tr.shifted_degrade_img if name != "base" else tr.degraded_img)
+        sd = dict(model.net.named_parameters())
+        for k in watch:
+            out[f"step_{name}_w::{k}"] = npy(sd[k])
+
+
+def main():
+    _stub_modules()
+    sys.path.insert(0, REF)
+    import scheduler as scheduler_mod
+    import sampler as sampler_mod
+    from models.unet import unet6
+    torch.set_num_threads(4)
+    jobs = {
+        "schedules": lambda o: gen_schedules(scheduler_mod, o),
+        "degrade": lambda o: gen_degrade(scheduler_mod, o),
+        "shift": lambda o: gen_shift(scheduler_mod, o),
+        "unet": lambda o: gen_unet(unet6, o),
+        "sampler": lambda o: gen_sampler(scheduler_mod, sampler_mod, unet6, o),
+        "train_step": lambda o: gen_train_step(scheduler_mod, unet6, o),
+    }
+    only = sys.argv[1:]
+    for name, fn in jobs.items():
+        if only and name not in only:
+            continue
+        o = {}
+        fn(o)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **o)
+        print(f"{name}: {len(o)} arrays -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()
