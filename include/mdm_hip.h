@@ -1,0 +1,217 @@
+/*
+ * mdm_hip.h -- C ABI of libmdm_hip.so: the MI355X (gfx950) kernels under the
+ * masked-diffusion train step and reverse sampler.
+ *
+ * The reference (hytae1993/masked-diffusion-model) has no FFI: its hot path is
+ * Python calling ATen ops.  Each entry point below replaces the ATen call sites
+ * named in its comment (file:line relative to /root/reference/code).  The Python
+ * host in masked-diffusion-model_amd/mdm binds these with ctypes and keeps the
+ * reference's Scheduler / Sampler / Trainer / model(x,t).sample surface.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the
+ *     name ends in _host.  The caller owns all buffers (incl. workspaces).
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered,
+ *     nothing synchronises, nothing allocates -> every call is graph-capturable.
+ *   - return 0 on success, negative on error; mdm_last_error() gives the
+ *     thread-local message.  Nothing throws across the ABI.
+ *   - dtype: MDM_F32 = 0 (exact-fp32 VALU contraction path, used for parity),
+ *            MDM_BF16 = 1 (bf16 storage, MFMA 16x16x32 contractions, fp32 accumulate).
+ *   - activations are NHWC with the channel count a multiple of 8; images enter
+ *     and leave as NCHW fp32 exactly like the reference's tensors.
+ */
+#ifndef MDM_HIP_H
+#define MDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDM_F32 0
+#define MDM_BF16 1
+
+const char* mdm_last_error(void);
+int mdm_version(void);
+/* number of visible HIP devices, or negative */
+int mdm_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Contractions.  One descriptor drives the three MFMA/VALU contraction
+ * kernels; it replaces F.conv2d (unet6.py:232-235) forward, its autograd
+ * dgrad/wgrad, F.linear (unet6.py:170-171), the 1x1 convs and the two einsums
+ * of AttentionBlock.qkv (unet6.py:316-324) plus their backward products.
+ *
+ * layout 0 (NT): D[m][n] = sum_k A[m][k] * B[n][k]      A rows gathered if conv
+ * layout 1 (NN): D[m][n] = sum_k A[m][k] * B[k][n]      A rows gathered if conv
+ * layout 2 (TN): D[m][n] = sum_k A[k][m] * B[k][n]      B rows gathered if conv
+ *
+ * conv != 0 turns the gathered operand into an implicit im2col over NHWC
+ * sources: row index = (img, oy, ox) over OH x OW, reduction index k = tap*Ck+c
+ * (layouts 0/1) or row index k = pixel with the tap taken from the grid
+ * (layout 2, weight gradient).  Two sources give the channel concat of
+ * unet6.py:501 without materialising it; ups=1 reads the source through a
+ * nearest x2 upsample (unet6.py:472); stride/pad_t/pad_l cover SamePad2d +
+ * stride-2 (unet6.py:257-272, 438-440); transposed=1 is the data-gradient form.
+ * ------------------------------------------------------------------------- */
+typedef struct mdm_gemm_desc {
+    int32_t dtype;              /* MDM_F32 | MDM_BF16: element type of A, B, sources, resid and (unless out_f32) D */
+    int32_t layout;             /* 0 NT, 1 NN, 2 TN */
+    int32_t M, N, K;
+    int32_t batch;              /* >= 1; blockIdx.z when conv == 0 */
+    int64_t sA, sB, sD, sR;     /* batch strides in elements */
+    const void* A; int32_t lda; int32_t _p0;
+    const void* B; int32_t ldb; int32_t _p1;
+    /* implicit-GEMM gather */
+    int32_t conv;
+    int32_t OH, OW;             /* row space of the gathered operand */
+    int32_t IH, IW;             /* logical source extent (after the virtual upsample) */
+    int32_t KH, KW, stride, pad_t, pad_l, transposed, ups;
+    int32_t C0, C1;             /* channels taken from src0 / src1 */
+    int32_t Ck;                 /* reduction channels per tap (layouts 0/1) */
+    const void* src0; const void* src1;
+    int32_t ld0, ld1;           /* pixel pitch of each source in elements */
+    int64_t wtap;               /* weight offset per tap in elements (layouts 0/1) */
+    /* epilogue */
+    void* D0; void* D1;         /* columns [0,N0) -> D0, [N0,N) -> D1 */
+    int32_t ldd0, ldd1, N0;
+    int32_t out_f32;            /* D is fp32 regardless of dtype */
+    float alpha;
+    int32_t acc0, acc1;         /* D += instead of D = */
+    const float* bias;          /* [N] or NULL */
+    const float* rowvec;        /* [M / rows_per_img][rv_ld] fp32 or NULL (time-embedding add, unet6.py:359) */
+    int32_t rv_ld, rows_per_img;
+    const void* resid;          /* [M][ldr] or NULL (residual add, unet6.py:333,362) */
+    int32_t ldr;
+    int32_t splitk;             /* layout 2 only: >1 => fp32 atomic accumulation into D0 */
+    int64_t dtap;               /* layout 2 + conv: D0 offset per tap */
+} mdm_gemm_desc;
+
+int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)
+ * x = concat(src0[C0], src1[C1]) along channels, NHWC, P = H*W pixels per image.
+ * stats: [N][G][2] fp32 (mean, rstd).  ws: [N][G][2] fp32 scratch, zeroed by the call.
+ * ------------------------------------------------------------------------- */
+int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1,
+                      int N, int P, int G, float eps, const float* gamma, const float* beta,
+                      int silu, void* y, float* stats, float* ws, void* stream);
+/* dx -> dst0/dst1 (channel split like the sources), acc flags add into them;
+ * dgamma/dbeta are ACCUMULATED (fp32 atomics).  ws: [N][G][2] fp32 scratch. */
+int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1,
+                      int N, int P, int G, const float* gamma, const float* beta, int silu,
+                      const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
+                      float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* row softmax of S[rows][L] in place (unet6.py:320-322), and its backward
+ * dS = P * (dP - sum_j dP*P) written over dP. */
+int mdm_softmax_fwd(int dtype, void* S, int rows, int L, void* stream);
+int mdm_softmax_bwd(int dtype, const void* P, void* dP, int rows, int L, void* stream);
+
+/* y[N][dim] = [sin(t*f) | cos(t*f)], f_i = exp(-i*ln(1e4)/(dim/2-1))  (unet6.py:18-34); fp32 */
+int mdm_timestep_embedding(const float* t, int N, int dim, float* y, void* stream);
+/* fp32 SiLU on small [n] vectors (unet6.py:397, 359) and its backward (dx = dy * silu'(x), acc adds) */
+int mdm_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int mdm_silu_bwd(const float* x, const float* dy, float* dx, int acc, int64_t n, void* stream);
+
+/* column sums of dY[N][P][C] (NHWC): per_img[n*ld + c] (= or +=) sum_p, and dbias[c] += sum_{n,p}.
+ * Either output may be NULL.  Backward of the bias add (unet6.py:233) and of the
+ * time-embedding broadcast add (unet6.py:359). */
+int mdm_colsum(int dtype, const void* dY, int N, int P, int C, float* per_img, int ld, int acc_img,
+               float* dbias, void* stream);
+
+/* 2x2 sum-pool of g[N][2H][2W][C] into dst[N][H][W][C] (backward of nn.Upsample(2,'nearest'), unet6.py:472) */
+int mdm_sumpool2(int dtype, const void* g, void* dst, int acc, int N, int H, int W, int C, void* stream);
+
+/* layout converters: NCHW fp32 <-> NHWC dtype with the channel count padded to Cp (pad = 0) */
+int mdm_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int Cp, void* stream);
+int mdm_nhwc_to_nchw(int dtype, const void* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Scheduler kernels (NCHW fp32, like the reference tensors)
+ * ------------------------------------------------------------------------- */
+/* On-device draw of the per-sample step (trainer_masked_mean_shift.py:109-112,
+ * scheduler.py:88-100, 780-794): idx ~ U{0..n_used-1}; t = used[idx]; amount = table[t-1];
+ * weight = wtab[idx] (or 1).  Philox4x32-10 keyed by rng[0]=seed, rng[1]=offset (device memory). */
+int mdm_draw_timesteps(const uint64_t* rng, const int32_t* used, int n_used, const double* table,
+                       const float* wtab, int N, float* t_out, double* amount_out, float* weight_out,
+                       int32_t* idx_out, void* stream);
+
+/* Thresholding mask + fill + degrade (scheduler.py:286-323 == 438-477 == 572-598).
+ *   u: [N][Cm*HW] uniforms (replay mode) or NULL (device Philox, stream id `rng_stream`);
+ *   mask_in: existing [N][C][HW] keep-mask to use instead of drawing (degrade_with_mask), or NULL;
+ *   amount: [N] double ratios (thresholding) ; Cm = 1 ('1-channel') or C ('3-channel');
+ *   fill_mode: 0 constant `fill_const`, 1 degraded_area image-wise, 2 degraded_area channel-wise,
+ *              3 non_degraded_area (NaN -> 0);
+ * outputs (any may be NULL): x_t, mask [N][C][HW] fp32, mean_pixel [N][C]. */
+int mdm_degrade(const float* x0, const float* u, const float* mask_in, const double* amount, int amount_stride,
+                const uint64_t* rng, int rng_stream, int N, int C, int HW, int Cm, int fill_mode, float fill_const,
+                float* x_t, float* mask, float* mean_pixel, void* stream);
+
+/* 'indexing' mode on device (scheduler.py:279-284): keep-mask [N][C][HW] with EXACTLY count[n] zeroed pixels
+ * per image (the count smallest of HW Philox keys; same distribution as randperm(HW)[:count], different
+ * stream).  The replay mode ships the host's randperm-built mask through mdm_degrade(mask_in=...). */
+int mdm_index_mask(const double* count, int count_stride, const uint64_t* rng, int rng_stream, int N, int C, int HW,
+                   float* mask, void* stream);
+
+/* Shift (scheduler.py:612-732) + perturb_shift (:757-766):  s = z * ratio,  x_in = x_t + s.
+ *   z: [N][zc][zhw] draws (replay) or NULL (device Philox normal(mean,1) / uniform(-1,1) per `kind`);
+ *   kind: 0 non_shift, 1 '1-d_constant' (zc=1,zhw=1,uniform), 2 '3-d_constant' (zc=3,zhw=1,uniform),
+ *         3 'noise_reduction' (zc=1,zhw=HW,normal), 4 'noise_with_perturbation' (zc=3,zhw=HW,normal);
+ *   ratio: [N] double; per_column != 0 reproduces the reference's N==W broadcast (ratio indexed by column w);
+ *   outputs: s [N][C][HW] (may be NULL), x_in fp32 NCHW (may be NULL), x_in_nhwc (dtype, Cp channels; may be NULL). */
+int mdm_shift(const float* x_t, const float* z, const double* ratio, const uint64_t* rng, int rng_stream,
+              int kind, float noise_mean, int per_column, int N, int C, int H, int W,
+              float* s, float* x_in, int dtype, void* x_in_nhwc, int Cp, void* stream);
+
+/* Fused x0-space loss + its gradient (trainer_masked_mean_shift.py:142-159, trainer_masked.py:126-140):
+ *   r = (x_in + pred) - s - x0 ;  loss += sum(w_n * r^2) / numel ;  dpred = 2 w_n r / numel * gscale
+ * pred, dpred: NHWC dtype with Cp channels (pad channels of dpred are written 0). s, w may be NULL. */
+int mdm_loss_fwd_bwd(int dtype, const void* pred, const float* x_in, const float* s, const float* x0,
+                     const float* w, int N, int C, int H, int W, int Cp, float gscale,
+                     void* dpred, float* loss_accum, void* stream);
+
+/* Reverse-step pieces (sampler.py:146-152, 199-216):
+ *   x0_hat = (x_in + pred) - s                                              (mdm_sampler_x0)
+ *   x_t   <- x_t + (d_next - d_t)  [momentum]  |  x_t <- d_next  [base]     (mdm_sampler_update) */
+int mdm_sampler_x0(int dtype, const void* pred_nhwc, int Cp, const float* x_in, const float* s,
+                   int N, int C, int H, int W, float* pred_nchw, float* shifted0, float* x0_hat, void* stream);
+int mdm_sampler_update(const float* d_t, const float* d_next, float* x_t, float* diff, int momentum,
+                       int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Optimizer: global-norm clip + AdamW + EMA + bf16 weight shadow in one pass over
+ * flat fp32 buffers (trainer_masked_mean_shift.py:163-172, main_train_masked.py:134-141).
+ *   hp (device, 8 floats): lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ema_decay
+ *   mdm_sqnorm accumulates sum(g^2) into *out (caller zeroes it).
+ *   clip_coef = min(1, max_norm / (sqrt(*sqnorm) * gscale_inv + 1e-6)); g is multiplied by gmul first
+ *   (gmul = 1/world for the DP mean).  ema / shadow may be NULL.
+ * ------------------------------------------------------------------------- */
+int mdm_sqnorm(const float* g, int64_t n, float* out, void* stream);
+int mdm_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16,
+                  int64_t n, const float* hp, const float* sqnorm, float max_norm, float gmul, void* stream);
+int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mdm_fill_f32(float* p, float v, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * hipGraph capture of a launch sequence issued on `stream` (the whole train step
+ * or one reverse step is ~10^3 short kernels: replay removes the host launch cost).
+ * ------------------------------------------------------------------------- */
+int mdm_graph_begin(void* stream);
+int mdm_graph_end(void* stream, void** graph_exec_out);
+int mdm_graph_launch(void* graph_exec, void* stream);
+int mdm_graph_destroy(void* graph_exec);
+
+/* HIP events on a caller-supplied stream (bench.py times kernels on the launch stream) */
+int mdm_event_create(void** ev);
+int mdm_event_record(void* ev, void* stream);
+int mdm_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);   /* synchronises on ev_stop */
+int mdm_event_destroy(void* ev);
+int mdm_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDM_HIP_H */

@@ -1,0 +1,484 @@
+// Contraction kernels for gfx950: one descriptor (mdm_gemm_desc), three operand
+// layouts (NT / NN / TN), optional implicit-im2col gather over NHWC sources.
+//
+//   bf16 path : 256-thread workgroups, 4 waves as 2x2, v_mfma_f32_16x16x32_bf16,
+//               tiles 128x128x64 or 64x64x64 staged through LDS (register-staged
+//               global loads so the gather can zero-fill and the rows can be padded
+//               against bank conflicts); k-strided operands are kept in their natural
+//               [k][col] image and read with ds_read_b64_tr_b16 (hardware transpose).
+//   fp32 path : exact-fp32 VALU contraction (64x64x16 tile, 4x4 per thread) used by
+//               the parity tests and the 1e-3 sampler check; shares every index
+//               function with the bf16 path.
+//
+// Replaces F.conv2d fwd/dgrad/wgrad, F.linear and the attention einsums
+// (reference unet6.py:170-171, 232-235, 316-324).
+#include "common.h"
+
+namespace mdm {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
+
+#ifndef MDM_USE_TR_READ
+#define MDM_USE_TR_READ 1
+#endif
+
+// ----------------------------------------------------------------------------
+// index helpers shared by both paths
+// ----------------------------------------------------------------------------
+struct RowPix { int img, oy, ox; };
+
+__device__ __forceinline__ RowPix decode_row(const mdm_gemm_desc& d, int row) {
+    RowPix r;
+    int per = d.OH * d.OW;
+    r.img = row / per;
+    int rem = row - r.img * per;
+    r.oy = rem / d.OW;
+    r.ox = rem - r.oy * d.OW;
+    return r;
+}
+
+// pointer to channel c of the source pixel that (row pixel, tap) reads; nullptr = zero padding
+template <typename T>
+__device__ __forceinline__ const T* gather_ptr(const mdm_gemm_desc& d, const RowPix& r, int tap, int c) {
+    int ty = tap / d.KW, tx = tap - ty * d.KW;
+    int iy, ix;
+    if (!d.transposed) {
+        iy = r.oy * d.stride + ty - d.pad_t;
+        ix = r.ox * d.stride + tx - d.pad_l;
+        if ((unsigned)iy >= (unsigned)d.IH || (unsigned)ix >= (unsigned)d.IW) return nullptr;
+    } else {
+        iy = r.oy + d.pad_t - ty;
+        ix = r.ox + d.pad_l - tx;
+        if (iy < 0 || ix < 0) return nullptr;
+        if (d.stride == 2) {
+            if ((iy | ix) & 1) return nullptr;
+            iy >>= 1; ix >>= 1;
+        }
+        if (iy >= d.IH || ix >= d.IW) return nullptr;
+    }
+    int sh = d.IH >> d.ups, sw = d.IW >> d.ups;
+    iy >>= d.ups; ix >>= d.ups;
+    int64_t spix = ((int64_t)r.img * sh + iy) * sw + ix;
+    if (c < d.C0) return reinterpret_cast<const T*>(d.src0) + spix * d.ld0 + c;
+    return reinterpret_cast<const T*>(d.src1) + spix * d.ld1 + (c - d.C0);
+}
+
+struct ZInfo { int batch, tap, kbeg, kend; };
+
+__device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
+    ZInfo z;
+    z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K;
+    int zi = blockIdx.z;
+    if (d.layout == 2) {
+        int sk = d.splitk < 1 ? 1 : d.splitk;
+        int outer = zi / sk, ks = zi - outer * sk;
+        if (d.conv) z.tap = outer; else z.batch = outer;
+        int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
+        z.kbeg = ks * chunk;
+        z.kend = min(d.K, z.kbeg + chunk);
+    } else {
+        z.batch = zi;
+    }
+    return z;
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z, int m, int n, float4 v) {
+    v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
+    if (d.bias) {
+        float4 b = *reinterpret_cast<const float4*>(d.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (d.rowvec) {
+        float4 b = *reinterpret_cast<const float4*>(d.rowvec + (int64_t)(m / d.rows_per_img) * d.rv_ld + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (d.resid) {
+        float4 b = load4(reinterpret_cast<const T*>(d.resid) + z.batch * d.sR + (int64_t)m * d.ldr + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    void* base; int ld, col, acc;
+    if (n < d.N0) { base = d.D0; ld = d.ldd0; col = n; acc = d.acc0; }
+    else          { base = d.D1; ld = d.ldd1; col = n - d.N0; acc = d.acc1; }
+    int64_t off = z.batch * d.sD + z.tap * d.dtap + (int64_t)m * ld + col;
+    if (d.layout == 2 && d.splitk > 1) {
+        float* p = reinterpret_cast<float*>(base) + off;
+        atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+    } else if (d.out_f32) {
+        float* p = reinterpret_cast<float*>(base) + off;
+        if (acc) { float4 o = load4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        store4(p, v);
+    } else {
+        T* p = reinterpret_cast<T*>(base) + off;
+        if (acc) { float4 o = load4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        store4(p, v);
+    }
+}
+
+// address of VEC consecutive k-elements of A-row `gm` starting at reduction index k (layouts 0/1)
+template <typename T>
+__device__ __forceinline__ const T* a_row_ptr(const mdm_gemm_desc& d, const ZInfo& z, int gm, const RowPix& rp, int k) {
+    if (gm >= d.M || k >= d.K) return nullptr;
+    if (d.conv) {
+        int tap = k / d.Ck, c = k - tap * d.Ck;
+        return gather_ptr<T>(d, rp, tap, c);
+    }
+    return reinterpret_cast<const T*>(d.A) + z.batch * d.sA + (int64_t)gm * d.lda + k;
+}
+// layout 0: VEC consecutive k of B-row gn
+template <typename T>
+__device__ __forceinline__ const T* b_row_ptr(const mdm_gemm_desc& d, const ZInfo& z, int gn, int k) {
+    if (gn >= d.N || k >= d.K) return nullptr;
+    const T* B = reinterpret_cast<const T*>(d.B) + z.batch * d.sB;
+    if (d.conv) {
+        int tap = k / d.Ck, c = k - tap * d.Ck;
+        return B + tap * d.wtap + (int64_t)gn * d.ldb + c;
+    }
+    return B + (int64_t)gn * d.ldb + k;
+}
+// layouts 1/2: VEC consecutive n of B k-row `k`
+template <typename T>
+__device__ __forceinline__ const T* b_col_ptr(const mdm_gemm_desc& d, const ZInfo& z, int k, int gn) {
+    if (gn >= d.N || k >= z.kend) return nullptr;
+    if (d.layout == 1) {
+        const T* B = reinterpret_cast<const T*>(d.B) + z.batch * d.sB;
+        if (d.conv) {
+            int tap = k / d.Ck, c = k - tap * d.Ck;
+            return B + tap * d.wtap + (int64_t)c * d.ldb + gn;
+        }
+        return B + (int64_t)k * d.ldb + gn;
+    }
+    if (d.conv) {
+        RowPix rp = decode_row(d, k);
+        return gather_ptr<T>(d, rp, z.tap, gn);
+    }
+    return reinterpret_cast<const T*>(d.B) + z.batch * d.sB + (int64_t)k * d.ldb + gn;
+}
+// layout 2: VEC consecutive m of A k-row `k`
+template <typename T>
+__device__ __forceinline__ const T* a_col_ptr(const mdm_gemm_desc& d, const ZInfo& z, int k, int gm) {
+    if (gm >= d.M || k >= z.kend) return nullptr;
+    return reinterpret_cast<const T*>(d.A) + z.batch * d.sA + (int64_t)k * d.lda + gm;
+}
+
+// ----------------------------------------------------------------------------
+// fp32 VALU path
+// ----------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(mdm_gemm_desc d) {
+    constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
+    __shared__ __attribute__((aligned(16))) float As[BK * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+    const int t = threadIdx.x;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const ZInfo z = decode_z(d, BK);
+
+    const int rr = t >> 2, rk = (t & 3) * 4;     // row-operand mapping: 64 rows x 4 vectors
+    const int ck = t >> 4, cc = (t & 15) * 4;    // col-operand mapping: 16 k-rows x 16 vectors
+    RowPix arow = {0, 0, 0};
+    if (LAYOUT != 2 && d.conv && m0 + rr < d.M) arow = decode_row(d, m0 + rr);
+
+    float acc[4][4] = {};
+    const int ty = t >> 4, tx = t & 15;
+    for (int k0 = z.kbeg; k0 < z.kend; k0 += BK) {
+        float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+        if (LAYOUT != 2) {
+            const float* p = a_row_ptr<float>(d, z, m0 + rr, arow, k0 + rk);
+            if (p) av = load4(p);
+        } else {
+            const float* p = a_col_ptr<float>(d, z, k0 + ck, m0 + cc);
+            if (p) av = load4(p);
+        }
+        if (LAYOUT == 0) {
+            const float* p = b_row_ptr<float>(d, z, n0 + rr, k0 + rk);
+            if (p) bv = load4(p);
+        } else {
+            const float* p = b_col_ptr<float>(d, z, k0 + ck, n0 + cc);
+            if (p) bv = load4(p);
+        }
+        __syncthreads();
+        if (LAYOUT != 2) {
+            As[(rk + 0) * LD + rr] = av.x; As[(rk + 1) * LD + rr] = av.y;
+            As[(rk + 2) * LD + rr] = av.z; As[(rk + 3) * LD + rr] = av.w;
+        } else {
+            *reinterpret_cast<float4*>(&As[ck * LD + cc]) = av;
+        }
+        if (LAYOUT == 0) {
+            Bs[(rk + 0) * LD + rr] = bv.x; Bs[(rk + 1) * LD + rr] = bv.y;
+            Bs[(rk + 2) * LD + rr] = bv.z; Bs[(rk + 3) * LD + rr] = bv.w;
+        } else {
+            *reinterpret_cast<float4*>(&Bs[ck * LD + cc]) = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            float4 a = *reinterpret_cast<const float4*>(&As[k * LD + ty * 4]);
+            float4 b = *reinterpret_cast<const float4*>(&Bs[k * LD + tx * 4]);
+            float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
+        }
+    }
+    const int n = n0 + tx * 4;
+    if (n < d.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = m0 + ty * 4 + i;
+            if (m < d.M) epilogue4<float>(d, z, m, n, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// bf16 MFMA path
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p) {
+    return p ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+}
+
+// fragment from a k-contiguous image [rows][BK+8]: lane -> row (l&15), k = 8*(l>>4)..+7
+template <int LDR>
+__device__ __forceinline__ bf16x8 frag_rows(const bf16_t* tile, int row0, int ks, int lane) {
+    const bf16_t* p = tile + (row0 + (lane & 15)) * LDR + ks * 32 + 8 * (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(p);
+}
+// fragment from a natural [k][cols+8] image: element j of lane l is tile[k = ks*32+8*(l>>4)+j][col0 + (l&15)]
+template <int LDC>
+__device__ __forceinline__ bf16x8 frag_cols(const bf16_t* tile, int col0, int ks, int lane) {
+    bf16x8 f;
+#if MDM_USE_TR_READ
+    const int i = lane & 15;
+    const int kb = ks * 32 + 8 * (lane >> 4);
+    const bf16_t* p0 = tile + (kb + (i >> 2)) * LDC + col0 + 4 * (i & 3);
+    const bf16_t* p1 = p0 + 4 * LDC;
+    bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(p0));
+    bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(p1));
+    bf16x4 l4 = *reinterpret_cast<bf16x4*>(&lo), h4 = *reinterpret_cast<bf16x4*>(&hi);
+    f[0] = l4[0]; f[1] = l4[1]; f[2] = l4[2]; f[3] = l4[3];
+    f[4] = h4[0]; f[5] = h4[1]; f[6] = h4[2]; f[7] = h4[3];
+#else
+    const bf16_t* p = tile + (ks * 32 + 8 * (lane >> 4)) * LDC + col0 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)p[j * LDC];
+#endif
+    return f;
+}
+
+template <int BM, int BN, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
+    constexpr int BK = 64;
+    constexpr bool A_ROWS = (LAYOUT != 2), B_ROWS = (LAYOUT == 0);
+    constexpr int LDA = A_ROWS ? BK + 8 : BM + 8;     // row pitch of the A image in elements
+    constexpr int LDB = B_ROWS ? BK + 8 : BN + 8;
+    constexpr int A_ELEMS = A_ROWS ? BM * LDA : BK * LDA;
+    constexpr int B_ELEMS = B_ROWS ? BN * LDB : BK * LDB;
+    constexpr int NVA = BM * BK / 8 / 256, NVB = BN * BK / 8 / 256;   // 16-byte vectors per thread
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[A_ELEMS + B_ELEMS];
+    bf16_t* As = smem;
+    bf16_t* Bs = smem + A_ELEMS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const ZInfo z = decode_z(d, BK);
+
+    // row-operand mapping: 8 vectors per row, 32 rows per pass
+    const int rr = t >> 3, rk = (t & 7) * 8;
+    // col-operand mapping
+    constexpr int AVR = BM / 8, BVR = BN / 8;          // vectors per k-row
+    constexpr int AKP = 256 / AVR, BKP = 256 / BVR;    // k-rows per pass
+    const int ack = t / AVR, acc_ = (t % AVR) * 8;
+    const int bck = t / BVR, bcc = (t % BVR) * 8;
+
+    RowPix arow[NVA];
+    if (A_ROWS && d.conv) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            int gm = m0 + rr + 32 * i;
+            arow[i] = decode_row(d, gm < d.M ? gm : 0);
+        }
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[NVA], rb[NVB];
+    auto load_tiles = [&](int k0) {
+        if (A_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i)
+                ra[i] = ldg16(a_row_ptr<bf16_t>(d, z, m0 + rr + 32 * i, arow[i], k0 + rk));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i)
+                ra[i] = ldg16(a_col_ptr<bf16_t>(d, z, k0 + ack + AKP * i, m0 + acc_));
+        }
+        if (B_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i)
+                rb[i] = ldg16(b_row_ptr<bf16_t>(d, z, n0 + rr + 32 * i, k0 + rk));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i)
+                rb[i] = ldg16(b_col_ptr<bf16_t>(d, z, k0 + bck + BKP * i, n0 + bcc));
+        }
+    };
+    auto store_tiles = [&]() {
+        if (A_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) *reinterpret_cast<uint4*>(&As[(rr + 32 * i) * LDA + rk]) = ra[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) *reinterpret_cast<uint4*>(&As[(ack + AKP * i) * LDA + acc_]) = ra[i];
+        }
+        if (B_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) *reinterpret_cast<uint4*>(&Bs[(rr + 32 * i) * LDB + rk]) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) *reinterpret_cast<uint4*>(&Bs[(bck + BKP * i) * LDB + bcc]) = rb[i];
+        }
+    };
+
+    load_tiles(z.kbeg);
+    for (int k0 = z.kbeg; k0 < z.kend; k0 += BK) {
+        __syncthreads();                // previous tile fully consumed
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < z.kend) load_tiles(k0 + BK);   // prefetch next tile into registers
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = A_ROWS ? frag_rows<LDA>(As, wr * WM + i * 16, ks, lane)
+                               : frag_cols<LDA>(As, wr * WM + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[j] = B_ROWS ? frag_rows<LDB>(Bs, wc * WN + j * 16, ks, lane)
+                                : frag_cols<LDB>(Bs, wc * WN + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    // operands swapped: the accumulator holds D[m = lane&15][n = 4*(lane>>4) + reg],
+                    // i.e. four consecutive output channels per lane -> 8/16-byte NHWC stores
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = m0 + wr * WM + i * 16 + (lane & 15);
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// host launch
+// ----------------------------------------------------------------------------
+static int validate(const mdm_gemm_desc& d) {
+    MDM_REQUIRE(d.dtype == MDM_F32 || d.dtype == MDM_BF16, "gemm: bad dtype %d", d.dtype);
+    MDM_REQUIRE(d.layout >= 0 && d.layout <= 2, "gemm: bad layout %d", d.layout);
+    MDM_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch >= 1, "gemm: bad dims M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
+    const int vec = d.dtype == MDM_BF16 ? 8 : 4;
+    MDM_REQUIRE(d.N % vec == 0, "gemm: N=%d must be a multiple of %d", d.N, vec);
+    MDM_REQUIRE(d.N0 % 4 == 0 && d.N0 > 0 && d.N0 <= d.N, "gemm: bad N0=%d (N=%d)", d.N0, d.N);
+    MDM_REQUIRE(d.D0 != nullptr && (d.N0 == d.N || d.D1 != nullptr), "gemm: missing destination");
+    MDM_REQUIRE(d.ldd0 % 4 == 0 && (d.D1 == nullptr || d.ldd1 % 4 == 0), "gemm: destination pitch must be a multiple of 4");
+    if (d.layout != 2) MDM_REQUIRE(d.K % vec == 0, "gemm: K=%d must be a multiple of %d in layouts 0/1", d.K, vec);
+    if (d.layout == 2) MDM_REQUIRE(d.M % vec == 0, "gemm: M=%d must be a multiple of %d in layout 2", d.M, vec);
+    if (d.conv) {
+        MDM_REQUIRE(d.batch == 1, "gemm: conv gather does not take a batch");
+        MDM_REQUIRE(d.src0 != nullptr && d.C0 > 0 && d.C0 % vec == 0 && d.C1 % vec == 0 && (d.C1 == 0 || d.src1 != nullptr),
+                    "gemm: bad sources C0=%d C1=%d", d.C0, d.C1);
+        MDM_REQUIRE(d.ld0 % vec == 0 && (d.C1 == 0 || d.ld1 % vec == 0), "gemm: source pitch must be a multiple of %d", vec);
+        MDM_REQUIRE(d.stride == 1 || d.stride == 2, "gemm: stride %d", d.stride);
+        MDM_REQUIRE(d.ups == 0 || d.ups == 1, "gemm: ups %d", d.ups);
+        MDM_REQUIRE(d.KH > 0 && d.KW > 0 && d.OH > 0 && d.OW > 0 && d.IH > 0 && d.IW > 0, "gemm: bad conv geometry");
+        MDM_REQUIRE(!d.ups || (d.IH % 2 == 0 && d.IW % 2 == 0), "gemm: upsampled extent must be even");
+        if (d.layout != 2) {
+            MDM_REQUIRE(d.Ck > 0 && d.Ck % vec == 0 && d.K == d.KH * d.KW * d.Ck, "gemm: K=%d != taps*Ck (Ck=%d)", d.K, d.Ck);
+            MDM_REQUIRE(d.B != nullptr, "gemm: missing weights");
+        } else {
+            MDM_REQUIRE(d.A != nullptr && d.N == d.C0 + d.C1, "gemm: wgrad N=%d must equal C0+C1", d.N);
+        }
+        if (d.layout == 0 || d.layout == 1) MDM_REQUIRE(!d.transposed || d.layout == 1 || d.layout == 0, "gemm");
+    } else {
+        MDM_REQUIRE(d.A != nullptr && d.B != nullptr, "gemm: missing operand");
+        MDM_REQUIRE(d.lda % vec == 0 && d.ldb % vec == 0, "gemm: operand pitch must be a multiple of %d", vec);
+    }
+    if (d.rowvec) MDM_REQUIRE(d.rows_per_img > 0 && d.rv_ld % 4 == 0, "gemm: bad rowvec params");
+    if (d.resid) MDM_REQUIRE(d.ldr % 4 == 0, "gemm: bad resid pitch");
+    if (d.layout == 2 && d.splitk > 1) MDM_REQUIRE(d.out_f32 || d.dtype == MDM_F32, "gemm: split-K needs an fp32 destination");
+    return 0;
+}
+
+template <int BM, int BN>
+static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    switch (d.layout) {
+        case 0: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 0>), grid, dim3(256), 0, s, d); break;
+        case 1: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 1>), grid, dim3(256), 0, s, d); break;
+        default: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 2>), grid, dim3(256), 0, s, d); break;
+    }
+}
+
+int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
+    MDM_REQUIRE(dh != nullptr, "gemm: null descriptor");
+    mdm_gemm_desc d = *dh;
+    if (d.N0 == 0) d.N0 = d.N;
+    if (int rc = validate(d)) return rc;
+    int zouter = d.batch;
+    if (d.layout == 2 && d.conv) zouter = d.KH * d.KW;
+    const bool big = d.dtype == MDM_BF16 &&
+                     (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= 200 && d.N >= 128 && d.M >= 128;
+    const int BM = d.dtype == MDM_F32 ? 64 : (big ? 128 : 64), BN = BM;
+    const int BK = d.dtype == MDM_F32 ? 16 : 64;
+    int64_t tiles = (int64_t)cdiv(d.M, BM) * cdiv(d.N, BN);
+    if (d.layout == 2) {
+        if (d.splitk <= 0) {     // auto: aim at ~1024 workgroups, at least 4 k-steps each
+            int64_t want = 1024 / (tiles * zouter);
+            int64_t cap = d.K / (4 * BK);
+            d.splitk = (int)(want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want));
+            if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
+        }
+    } else {
+        d.splitk = 1;
+    }
+    MDM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
+    dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * (d.layout == 2 ? d.splitk : 1)));
+    MDM_REQUIRE(grid.z <= 65535, "gemm: grid.z=%u too large", grid.z);
+    if (d.dtype == MDM_F32) {
+        switch (d.layout) {
+            case 0: hipLaunchKernelGGL((gemm_f32_kernel<0>), grid, dim3(256), 0, s, d); break;
+            case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
+            default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
+        }
+    } else if (big) {
+        launch_bf16<128, 128>(d, grid, s);
+    } else {
+        launch_bf16<64, 64>(d, grid, s);
+    }
+    return launch_status("gemm launch");
+}
+
+}  // namespace mdm
+
+extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
+    return mdm::gemm_launch(desc_host, reinterpret_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,84 @@
+// Optimizer pass over flat fp32 buffers: global grad-norm, clip, AdamW, EMA and the
+// bf16 weight shadow in one read-modify-write sweep (HBM-bound: 16 B read + 12..18 B
+// written per parameter).
+//
+// Replaces accelerator.clip_grad_norm_ + torch.optim.AdamW.step + diffusers EMAModel.step
+// (reference trainer_masked_mean_shift.py:163-172, main_train_masked.py:116-141).
+#include "common.h"
+
+namespace mdm {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n4, int64_t n, float* out) {
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(g)[i];
+        a = fmaf(v.x, v.x, a); a = fmaf(v.y, v.y, a); a = fmaf(v.z, v.z, a); a = fmaf(v.w, v.w, a);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 * 4; i < n; ++i) a = fmaf(g[i], g[i], a);
+    a = wave_sum(a);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// hp: lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ema_decay
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, float* ema, bf16_t* shadow,
+                                                    int64_t n, const float* hp, const float* sqnorm, float max_norm, float gmul) {
+    const float lr = hp[0], b1 = hp[1], b2 = hp[2], eps = hp[3], wd = hp[4], bc1 = hp[5], bc2 = hp[6], ed = hp[7];
+    float coef = gmul;
+    if (max_norm > 0.f) {
+        float norm = sqrtf(*sqnorm) * gmul;
+        float c = max_norm / (norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+        if (c < 1.f) coef *= c;
+    }
+    const float step = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * coef;
+        float pi = p[i] * (1.f - lr * wd);            // decoupled weight decay first (torch AdamW)
+        float mi = b1 * m[i] + (1.f - b1) * gi;
+        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        pi -= step * mi / denom;
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (ema) { float e = ema[i]; ema[i] = e - (1.f - ed) * (e - pi); }
+        if (shadow) shadow[i] = f2bf(pi);
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
+}
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static inline int ogrid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+}  // namespace mdm
+using namespace mdm;
+
+extern "C" int mdm_sqnorm(const float* g, int64_t n, float* out, void* stream) {
+    MDM_REQUIRE(g && out && n > 0, "sqnorm: bad arguments");
+    MDM_REQUIRE(((uintptr_t)g & 15) == 0, "sqnorm: buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(ogrid(n / 4)), dim3(256), 0, (hipStream_t)stream, g, n / 4, n, out);
+    return launch_status("sqnorm");
+}
+extern "C" int mdm_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n,
+                             const float* hp, const float* sqnorm, float max_norm, float gmul, void* stream) {
+    MDM_REQUIRE(p && g && m && v && hp && n > 0, "adamw: bad arguments");
+    MDM_REQUIRE(max_norm <= 0.f || sqnorm, "adamw: clipping needs the squared norm");
+    hipLaunchKernelGGL(adamw_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)shadow_bf16, n, hp,
+                       sqnorm, max_norm, gmul);
+    return launch_status("adamw");
+}
+extern "C" int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    return launch_status("cast_bf16");
+}
+extern "C" int mdm_fill_f32(float* p, float v, int64_t n, void* stream) {
+    hipLaunchKernelGGL(fill_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+    return launch_status("fill");
+}

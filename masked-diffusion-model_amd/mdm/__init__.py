@@ -1,0 +1,10 @@
+"""mdm -- MI355X-native masked-diffusion train step and reverse sampler.
+
+Host side (Python on PyTorch-ROCm for device memory / streams / torch.distributed)
+over libmdm_hip.so (hand-written HIP kernels for gfx950, C ABI in include/mdm_hip.h).
+Keeps the reference's call surface: Scheduler(args), Sampler(dataset, args, Scheduler,
+dataset_hist).sample(model, timesteps), Trainer(...).train(...), model(x, t).sample.
+"""
+from . import _lib  # noqa: F401
+
+__all__ = ["_lib"]

@@ -1,0 +1,133 @@
+"""ctypes binding of libmdm_hip.so (include/mdm_hip.h).
+
+The product path has NO fallback: if the shared library is missing, or a call
+returns non-zero, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `mdm_gemm_desc` (include/mdm_hip.h)."""
+    _fields_ = [
+        ("dtype", i32), ("layout", i32), ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+        ("sA", i64), ("sB", i64), ("sD", i64), ("sR", i64),
+        ("A", vp), ("lda", i32), ("_p0", i32),
+        ("B", vp), ("ldb", i32), ("_p1", i32),
+        ("conv", i32), ("OH", i32), ("OW", i32), ("IH", i32), ("IW", i32),
+        ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32), ("transposed", i32), ("ups", i32),
+        ("C0", i32), ("C1", i32), ("Ck", i32),
+        ("src0", vp), ("src1", vp), ("ld0", i32), ("ld1", i32), ("wtap", i64),
+        ("D0", vp), ("D1", vp), ("ldd0", i32), ("ldd1", i32), ("N0", i32), ("out_f32", i32), ("alpha", f32),
+        ("acc0", i32), ("acc1", i32), ("bias", vp), ("rowvec", vp), ("rv_ld", i32), ("rows_per_img", i32),
+        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64),
+    ]
+
+
+_PROTOS = {
+    "mdm_version": ([], i32),
+    "mdm_device_count": ([], i32),
+    "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
+    "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
+    "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
+    "mdm_softmax_fwd": ([i32, vp, i32, i32, vp], i32),
+    "mdm_softmax_bwd": ([i32, vp, vp, i32, i32, vp], i32),
+    "mdm_timestep_embedding": ([vp, i32, i32, vp, vp], i32),
+    "mdm_silu_fwd": ([vp, vp, i64, vp], i32),
+    "mdm_silu_bwd": ([vp, vp, vp, i32, i64, vp], i32),
+    "mdm_colsum": ([i32, vp, i32, i32, i32, vp, i32, i32, vp, vp], i32),
+    "mdm_sumpool2": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "mdm_nchw_to_nhwc": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "mdm_nhwc_to_nchw": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "mdm_draw_timesteps": ([vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),
+    "mdm_degrade": ([vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp], i32),
+    "mdm_index_mask": ([vp, i32, vp, i32, i32, i32, i32, vp, vp], i32),
+    "mdm_shift": ([vp, vp, vp, vp, i32, i32, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp], i32),
+    "mdm_loss_fwd_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp], i32),
+    "mdm_sampler_x0": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp], i32),
+    "mdm_sampler_update": ([vp, vp, vp, vp, i32, i64, vp], i32),
+    "mdm_sqnorm": ([vp, i64, vp, vp], i32),
+    "mdm_adamw_ema": ([vp, vp, vp, vp, vp, vp, i64, vp, vp, f32, f32, vp], i32),
+    "mdm_cast_bf16": ([vp, vp, i64, vp], i32),
+    "mdm_fill_f32": ([vp, f32, i64, vp], i32),
+    "mdm_graph_begin": ([vp], i32),
+    "mdm_graph_end": ([vp, C.POINTER(vp)], i32),
+    "mdm_graph_launch": ([vp, vp], i32),
+    "mdm_graph_destroy": ([vp], i32),
+    "mdm_event_create": ([C.POINTER(vp)], i32),
+    "mdm_event_record": ([vp, vp], i32),
+    "mdm_event_elapsed_ms": ([vp, vp, C.POINTER(f32)], i32),
+    "mdm_event_destroy": ([vp], i32),
+    "mdm_stream_sync": ([vp], i32),
+}
+
+EXPORTS = ["mdm_last_error"] + list(_PROTOS)
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C masked-diffusion-model_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mdm_last_error.restype = C.c_char_p
+    lib.mdm_last_error.argtypes = []
+    for name, (args, res) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"libmdm_hip {what} failed ({rc}): {load().mdm_last_error().decode()}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    """The HIP stream kernels are launched on: torch's current stream of the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def torch_dtype(dt):
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def gemm(**kw):
+    d = GemmDesc()
+    d.alpha = 1.0
+    d.batch = 1
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(d, k, v)
+    call("mdm_gemm", C.byref(d), stream())
+    return d

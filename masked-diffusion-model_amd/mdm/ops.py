@@ -1,0 +1,146 @@
+"""Host-side launchers: build `mdm_gemm_desc`s and call the C ABI.
+
+Every function enqueues kernels on torch's current stream and returns at once.
+Tensors are NHWC (`[N, H, W, C]`, C a multiple of 8) unless stated otherwise.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, call, ptr, stream
+
+
+@dataclass
+class ConvGeom:
+    """Geometry of one convolution site (reference unet6.py:232-235, 257-272, 472-475)."""
+    N: int
+    IH: int          # physical source extent
+    IW: int
+    C0: int          # channels of source 0 / source 1 (concat, unet6.py:501)
+    C1: int
+    Cout: int
+    KH: int = 3
+    KW: int = 3
+    stride: int = 1
+    pad_t: int = 1
+    pad_l: int = 1
+    pad_b: int = 1
+    pad_r: int = 1
+    ups: int = 0     # read the source through a nearest x2 upsample
+
+    @property
+    def Cin(self):
+        return self.C0 + self.C1
+
+    @property
+    def VH(self):    # logical (virtual) input extent
+        return self.IH << self.ups
+
+    @property
+    def VW(self):
+        return self.IW << self.ups
+
+    @property
+    def OH(self):
+        return (self.VH + self.pad_t + self.pad_b - self.KH) // self.stride + 1
+
+    @property
+    def OW(self):
+        return (self.VW + self.pad_l + self.pad_r - self.KW) // self.stride + 1
+
+    @property
+    def taps(self):
+        return self.KH * self.KW
+
+
+def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0):
+    """out[N,OH,OW,Cout] = conv(concat(src0,src1), w[tap][Cout][Cin]) + bias + rowvec[n] + resid."""
+    _lib.gemm(dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
+              conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
+              pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
+              src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, B=w, ldb=g.Cin, wtap=g.Cout * g.Cin,
+              D0=out, ldd0=g.Cout, N0=g.Cout, out_f32=out_f32, bias=bias, rowvec=rowvec, rv_ld=rv_ld,
+              rows_per_img=g.OH * g.OW, resid=resid, ldr=g.Cout)
+
+
+def conv_dgrad(dt, g: ConvGeom, dy, w, dst0, acc0, dst1=None, acc1=0):
+    """Gradient w.r.t. the (virtual) input: dst[N,VH,VW,C0|C1] (=|+=) conv_transpose(dy, w)."""
+    _lib.gemm(dtype=dt, layout=1, M=g.N * g.VH * g.VW, N=g.Cin, K=g.taps * g.Cout,
+              conv=1, OH=g.VH, OW=g.VW, IH=g.OH, IW=g.OW, KH=g.KH, KW=g.KW, stride=g.stride,
+              pad_t=g.pad_t, pad_l=g.pad_l, transposed=1, ups=0, C0=g.Cout, C1=0, Ck=g.Cout,
+              src0=dy, src1=None, ld0=g.Cout, ld1=0, B=w, ldb=g.Cin, wtap=g.Cout * g.Cin,
+              D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1)
+
+
+def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0):
+    """dw[tap][Cout][Cin] (fp32) += sum_pixels dy x gathered input."""
+    _lib.gemm(dtype=dt, layout=2, M=g.Cout, N=g.Cin, K=g.N * g.OH * g.OW,
+              conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
+              pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
+              src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, A=dy, lda=g.Cout,
+              D0=dw, ldd0=g.Cin, N0=g.Cin, out_f32=1, acc0=1, splitk=splitk, dtap=g.Cout * g.Cin)
+
+
+def matmul(dt, layout, M, N, K, A, lda, B, ldb, D, ldd, batch=1, sA=0, sB=0, sD=0, alpha=1.0, bias=None,
+           acc=0, out_f32=0, splitk=1):
+    """Plain (batched) contraction in one of the three layouts (see mdm_hip.h)."""
+    _lib.gemm(dtype=dt, layout=layout, M=M, N=N, K=K, batch=batch, sA=sA, sB=sB, sD=sD, A=A, lda=lda, B=B, ldb=ldb,
+              D0=D, ldd0=ldd, N0=N, alpha=alpha, bias=bias, acc0=acc, out_f32=out_f32, splitk=splitk)
+
+
+def groupnorm_fwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, y, stats, ws, G=32, eps=1e-6):
+    call("mdm_groupnorm_fwd", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, eps, ptr(gamma), ptr(beta), int(silu),
+         ptr(y), ptr(stats), ptr(ws), stream())
+
+
+def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, dst0, acc0, dst1, acc1,
+                  dgamma, dbeta, ws, G=32):
+    call("mdm_groupnorm_bwd", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
+         ptr(stats), ptr(dst0), int(acc0), ptr(dst1), int(acc1), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+
+
+def softmax_fwd(dt, S, rows, L):
+    call("mdm_softmax_fwd", dt, ptr(S), rows, L, stream())
+
+
+def softmax_bwd(dt, P, dP, rows, L):
+    call("mdm_softmax_bwd", dt, ptr(P), ptr(dP), rows, L, stream())
+
+
+def timestep_embedding(t, N, dim, y):
+    call("mdm_timestep_embedding", ptr(t), N, dim, ptr(y), stream())
+
+
+def silu_fwd(x, y, n):
+    call("mdm_silu_fwd", ptr(x), ptr(y), n, stream())
+
+
+def silu_bwd(x, dy, dx, acc, n):
+    call("mdm_silu_bwd", ptr(x), ptr(dy), ptr(dx), int(acc), n, stream())
+
+
+def colsum(dt, dY, N, P, C, per_img=None, ld=0, acc_img=0, dbias=None):
+    call("mdm_colsum", dt, ptr(dY), N, P, C, ptr(per_img), ld, int(acc_img), ptr(dbias), stream())
+
+
+def sumpool2(dt, g, dst, acc, N, H, W, C):
+    call("mdm_sumpool2", dt, ptr(g), ptr(dst), int(acc), N, H, W, C, stream())
+
+
+def nchw_to_nhwc(dt, x, y, N, C, H, W, Cp):
+    call("mdm_nchw_to_nhwc", dt, ptr(x), ptr(y), N, C, H, W, Cp, stream())
+
+
+def nhwc_to_nchw(dt, x, y, N, C, H, W, Cp):
+    call("mdm_nhwc_to_nchw", dt, ptr(x), ptr(y), N, C, H, W, Cp, stream())
+
+
+def fill(t, v):
+    call("mdm_fill_f32", ptr(t), float(v), t.numel(), stream())
+
+
+def cast_bf16(src, dst):
+    call("mdm_cast_bf16", ptr(src), ptr(dst), src.numel(), stream())

@@ -1,0 +1,256 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain torch
+fp32 on the CPU.  fp32 path: tight tolerance (same arithmetic, different summation
+order).  bf16 path: inputs are pre-rounded to bf16 so only accumulation order and the
+final bf16 store differ."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": 0, "bf16": 1}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _q(x, dt):
+    """Round to the storage type (CPU copy stays fp32 for the checker)."""
+    return x.bfloat16().float() if dt == "bf16" else x
+
+
+def _up(x, dt):
+    return x.to(_dev(), torch.bfloat16 if dt == "bf16" else torch.float32).contiguous()
+
+
+def _tol(dt, scale=1.0):
+    return (2e-2 if dt == "bf16" else 2e-4) * scale
+
+
+def _relerr(a, b):
+    return float((a.float().cpu() - b).norm() / (b.norm() + 1e-12))
+
+
+def _nhwc(x):      # NCHW -> NHWC
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _w_tap(w):     # OIHW -> [tap][O][I]
+    o, i, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, o, i).contiguous()
+
+
+CONV_CASES = [
+    # N, H, C0, C1, Cout, K, stride, pads(t,l,b,r), ups
+    (2, 8, 16, 0, 32, 3, 1, (1, 1, 1, 1), 0),
+    (2, 8, 8, 24, 40, 3, 1, (1, 1, 1, 1), 0),       # concat, odd-ish channel counts
+    (3, 8, 32, 0, 32, 3, 2, (0, 0, 1, 1), 0),       # SamePad2d(3,2) + stride 2
+    (2, 4, 24, 0, 16, 3, 1, (1, 1, 1, 1), 1),       # nearest x2 upsample folded into the gather
+    (2, 8, 64, 32, 48, 1, 1, (0, 0, 0, 0), 0),      # 1x1 skip conv over a concat
+    (4, 16, 128, 0, 128, 3, 1, (1, 1, 1, 1), 0),    # big enough for several tiles
+]
+
+
+def _conv_ref(x0, x1, w, b, stride, pads, ups):
+    x = torch.cat([x0, x1], 1) if x1 is not None else x0
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    t, l, bb, r = pads
+    x = F.pad(x, (l, r, t, bb))
+    return F.conv2d(x, w, b, stride=stride)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dt, case):
+    from mdm import ops
+    N, H, C0, C1, Cout, K, stride, pads, ups = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x0 = _q(torch.randn(N, C0, H, H, generator=g), dt).requires_grad_(True)
+    x1 = _q(torch.randn(N, C1, H, H, generator=g), dt).requires_grad_(True) if C1 else None
+    w = _q(torch.randn(Cout, C0 + C1, K, K, generator=g) / math.sqrt((C0 + C1) * K * K), dt).requires_grad_(True)
+    b = torch.randn(Cout, generator=g)
+    y = _conv_ref(x0, x1, w, b, stride, pads, ups)
+    gy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(gy)
+
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, KH=K, KW=K, stride=stride,
+                        pad_t=pads[0], pad_l=pads[1], pad_b=pads[2], pad_r=pads[3], ups=ups)
+    assert (geom.OH, geom.OW) == tuple(y.shape[2:])
+    d0 = _up(_nhwc(x0.detach()), dt)
+    d1 = _up(_nhwc(x1.detach()), dt) if C1 else None
+    dw_ = _up(_w_tap(w.detach()), dt)
+    db = b.to(_dev())
+    out = torch.empty(N, geom.OH, geom.OW, Cout, device=_dev(), dtype=d0.dtype)
+    ops.conv_fwd(DT[dt], geom, d0, d1, dw_, db, out)
+    torch.cuda.synchronize()
+    assert _relerr(out, _nhwc(y.detach())) < _tol(dt)
+
+    # data gradient (through the virtual, upsampled extent; pooled afterwards like the model does)
+    dgy = _up(_nhwc(gy), dt)
+    gx0 = torch.zeros(N, geom.VH, geom.VW, C0, device=_dev(), dtype=d0.dtype)
+    gx1 = torch.zeros(N, geom.VH, geom.VW, C1, device=_dev(), dtype=d0.dtype) if C1 else None
+    ops.conv_dgrad(DT[dt], geom, dgy, dw_, gx0, 0, gx1, 0)
+    if ups:
+        p0 = torch.empty(N, H, H, C0, device=_dev(), dtype=d0.dtype)
+        ops.sumpool2(DT[dt], gx0, p0, 0, N, H, H, C0)
+        gx0 = p0
+    torch.cuda.synchronize()
+    assert _relerr(gx0, _nhwc(x0.grad)) < _tol(dt, 1.5)
+    if C1:
+        assert _relerr(gx1, _nhwc(x1.grad)) < _tol(dt, 1.5)
+
+    # weight gradient, fp32 accumulate (+= on top of an existing value)
+    gw = torch.full((K * K, Cout, C0 + C1), 0.5, device=_dev(), dtype=torch.float32)
+    ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw)
+    torch.cuda.synchronize()
+    assert _relerr(gw - 0.5, _w_tap(w.grad)) < _tol(dt, 0.5 if dt == "bf16" else 1.0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_epilogue_rowvec_resid_accumulate(dt):
+    from mdm import ops
+    N, H, C, Cout = 2, 8, 32, 64
+    g = torch.Generator().manual_seed(3)
+    x = _q(torch.randn(N, C, H, H, generator=g), dt)
+    w = _q(torch.randn(Cout, C, 3, 3, generator=g) / 17.0, dt)
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(N, 96, generator=g)            # slice [16:16+Cout] of a wider time-embedding table
+    res = _q(torch.randn(N, Cout, H, H, generator=g), dt)
+    y = F.conv2d(x, w, b, padding=1) + rv[:, 16:16 + Cout, None, None] + res
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
+    out = torch.empty(N, H, H, Cout, device=_dev(), dtype=_up(x, dt).dtype)
+    rvd = rv.to(_dev())
+    ops.conv_fwd(DT[dt], geom, _up(_nhwc(x), dt), None, _up(_w_tap(w), dt), b.to(_dev()), out,
+                 rowvec=rvd[:, 16:], rv_ld=96, resid=_up(_nhwc(res), dt))
+    torch.cuda.synchronize()
+    assert _relerr(out, _nhwc(y)) < _tol(dt)
+    # dgrad accumulation into an existing gradient
+    gy = _q(torch.randn(N, Cout, H, H, generator=g), dt)
+    base = _q(torch.randn(N, C, H, H, generator=g), dt)
+    want = base + F.conv_transpose2d(gy, w, padding=1)
+    dst = _up(_nhwc(base), dt).clone()
+    ops.conv_dgrad(DT[dt], geom, _up(_nhwc(gy), dt), _up(_w_tap(w), dt), dst, 1)
+    torch.cuda.synchronize()
+    assert _relerr(dst, _nhwc(want)) < _tol(dt, 1.5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 64, 256), (2, 16, 16, 64), (2, 256, 256, 64), (1, 40, 72, 136)])
+def test_batched_matmul_layouts(dt, shape):
+    """The three operand layouts on the attention-sized products (unet6.py:316-324)."""
+    from mdm import ops
+    B, M, N, K = shape
+    g = torch.Generator().manual_seed(7)
+    dev = _dev()
+    a_mk = _q(torch.randn(B, M, K, generator=g), dt)
+    a_km = a_mk.transpose(1, 2).contiguous()
+    b_nk = _q(torch.randn(B, N, K, generator=g), dt)
+    b_kn = b_nk.transpose(1, 2).contiguous()
+    want = torch.einsum("bmk,bnk->bmn", a_mk, b_nk) * 0.25
+    for layout, A, lda, Bm, ldb in ((0, a_mk, K, b_nk, K), (1, a_mk, K, b_kn, N), (2, a_km, M, b_kn, N)):
+        D = torch.empty(B, M, N, device=dev, dtype=_up(a_mk, dt).dtype)
+        ops.matmul(DT[dt], layout, M, N, K, _up(A, dt), lda, _up(Bm, dt), ldb, D, N, batch=B, sA=M * K, sB=N * K,
+                   sD=M * N, alpha=0.25)
+        torch.cuda.synchronize()
+        assert _relerr(D, want) < _tol(dt), f"layout {layout}"
+    # layout 2 with split-K into an fp32 destination that already holds a value
+    D = torch.full((B, M, N), 1.0, device=dev, dtype=torch.float32)
+    ops.matmul(DT[dt], 2, M, N, K, _up(a_km, dt), M, _up(b_kn, dt), N, D, N, batch=B, sA=M * K, sB=N * K, sD=M * N,
+               alpha=0.25, out_f32=1, splitk=2)
+    torch.cuda.synchronize()
+    assert _relerr(D - 1.0, want) < _tol(dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C0,C1,HW,silu", [(128, 0, 64, True), (256, 128, 16, True), (32, 0, 256, False), (64, 32, 64, True)])
+def test_groupnorm_fwd_bwd(dt, C0, C1, HW, silu):
+    from mdm import ops
+    N, G = 3, 32
+    C = C0 + C1
+    g = torch.Generator().manual_seed(C + HW)
+    x = _q(torch.randn(N, C, HW, generator=g) * 1.5 + 0.3, dt).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    y = F.group_norm(x, G, gamma, beta, eps=1e-6)
+    if silu:
+        y = F.silu(y)
+    gy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(gy)
+    dev = _dev()
+    xh = x.detach().permute(0, 2, 1).contiguous()          # [N, HW, C]
+    s0 = _up(xh[..., :C0], dt)
+    s1 = _up(xh[..., C0:], dt) if C1 else None
+    out = torch.empty(N, HW, C, device=dev, dtype=s0.dtype)
+    stats = torch.empty(N, G, 2, device=dev)
+    ws = torch.empty(N, G, 2, device=dev)
+    gd, bd = gamma.detach().to(dev), beta.detach().to(dev)
+    ops.groupnorm_fwd(DT[dt], s0, C0, s1, C1, N, HW, gd, bd, silu, out, stats, ws)
+    torch.cuda.synchronize()
+    assert _relerr(out, y.detach().permute(0, 2, 1)) < _tol(dt, 0.5)
+    d0 = torch.empty_like(s0)
+    d1 = torch.empty_like(s1) if C1 else None
+    dg = torch.zeros(C, device=dev)
+    db = torch.zeros(C, device=dev)
+    ops.groupnorm_bwd(DT[dt], s0, C0, s1, C1, N, HW, gd, bd, silu, _up(gy.permute(0, 2, 1), dt), stats, d0, 0, d1, 0, dg, db, ws)
+    torch.cuda.synchronize()
+    gx = x.grad.permute(0, 2, 1)
+    assert _relerr(d0, gx[..., :C0]) < _tol(dt)
+    if C1:
+        assert _relerr(d1, gx[..., C0:]) < _tol(dt)
+    assert _relerr(dg, gamma.grad) < _tol(dt, 0.25)
+    assert _relerr(db, beta.grad) < _tol(dt, 0.25)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_softmax_colsum_pool_layout_temb(dt):
+    from mdm import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    S = _q(torch.randn(96, 64, generator=g) * 3, dt).requires_grad_(True)
+    P = torch.softmax(S, -1)
+    gp = _q(torch.randn(96, 64, generator=g), dt)
+    P.backward(gp)
+    Sd = _up(S.detach(), dt)
+    ops.softmax_fwd(DT[dt], Sd, 96, 64)
+    torch.cuda.synchronize()
+    assert _relerr(Sd, P.detach()) < _tol(dt, 0.5)
+    gd = _up(gp, dt)
+    ops.softmax_bwd(DT[dt], _up(P.detach(), dt), gd, 96, 64)
+    torch.cuda.synchronize()
+    assert _relerr(gd, S.grad) < _tol(dt)
+    # column sums
+    dY = _q(torch.randn(3, 50, 72, generator=g), dt)
+    per = torch.ones(3, 80, device=dev)
+    dbias = torch.ones(72, device=dev)
+    ops.colsum(DT[dt], _up(dY, dt), 3, 50, 72, per_img=per[:, 8:], ld=80, acc_img=1, dbias=dbias)
+    torch.cuda.synchronize()
+    assert _relerr(per[:, 8:] - 1, dY.sum(1)) < 1e-5
+    assert _relerr(dbias - 1, dY.sum((0, 1))) < 1e-5
+    assert float(per[:, :8].sum()) == 24.0
+    # 2x2 sum pool
+    up = _q(torch.randn(2, 8, 8, 16, generator=g), dt)
+    dst = torch.empty(2, 4, 4, 16, device=dev, dtype=_up(up, dt).dtype)
+    ops.sumpool2(DT[dt], _up(up, dt), dst, 0, 2, 4, 4, 16)
+    torch.cuda.synchronize()
+    want = up.reshape(2, 4, 2, 4, 2, 16).sum((2, 4))
+    assert _relerr(dst, want) < _tol(dt, 0.5)
+    # layout converters round-trip with channel padding
+    x = _q(torch.randn(2, 3, 8, 8, generator=g), dt)
+    xh = torch.empty(2, 8, 8, 8, device=dev, dtype=dst.dtype)
+    ops.nchw_to_nhwc(DT[dt], x.to(dev), xh, 2, 3, 8, 8, 8)
+    back = torch.empty(2, 3, 8, 8, device=dev)
+    ops.nhwc_to_nchw(DT[dt], xh, back, 2, 3, 8, 8, 8)
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x) and float(xh[..., 3:].float().abs().sum()) == 0.0
+    if dt == "f32":
+        from oracle.unet_ref import timestep_embedding
+        t = torch.tensor([1.0, 17.0, 500.0, 1000.0])
+        y = torch.empty(4, 128, device=dev)
+        ops.timestep_embedding(t.to(dev), 4, 128, y)
+        torch.cuda.synchronize()
+        assert (y.cpu() - timestep_embedding(t, 128)).abs().max() < 2e-4   # sin/cos of arguments up to 1e3
