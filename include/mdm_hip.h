@@ -125,6 +125,9 @@ int mdm_colsum(int dtype, const void* dY, int N, int P, int C, float* per_img, i
 /* 2x2 sum-pool of g[N][2H][2W][C] into dst[N][H][W][C] (backward of nn.Upsample(2,'nearest'), unet6.py:472) */
 int mdm_sumpool2(int dtype, const void* g, void* dst, int acc, int N, int H, int W, int C, void* stream);
 
+/* dst += src over n elements of `dtype` (n % 8 == 0): joins two gradient contributions of one activation */
+int mdm_add(int dtype, void* dst, const void* src, int64_t n, void* stream);
+
 /* layout converters: NCHW fp32 <-> NHWC dtype with the channel count padded to Cp (pad = 0) */
 int mdm_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int Cp, void* stream);
 int mdm_nhwc_to_nchw(int dtype, const void* x, float* y, int N, int C, int H, int W, int Cp, void* stream);

@@ -298,6 +298,16 @@ __global__ void nhwc_to_nchw_kernel(const T* x, float* y, int C, int HW, int Cp,
     y[i] = Elem<T>::ld(x + (img * HW + p) * Cp + c);
 }
 
+template <typename T>
+__global__ void add_kernel(T* dst, const T* src, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float8 a = load8(dst + i * 8), b = load8(src + i * 8);
+        a.lo.x += b.lo.x; a.lo.y += b.lo.y; a.lo.z += b.lo.z; a.lo.w += b.lo.w;
+        a.hi.x += b.hi.x; a.hi.y += b.hi.y; a.hi.z += b.hi.z; a.hi.w += b.hi.w;
+        store8(dst + i * 8, a);
+    }
+}
+
 __global__ void temb_kernel(const float* t, int N, int dim, float* y) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int half = dim / 2;
@@ -422,6 +432,12 @@ extern "C" int mdm_sumpool2(int dtype, const void* g, void* dst, int acc, int N,
     const int64_t tv = (int64_t)N * H * W * (C / 8);
     DISPATCH_T(dtype, hipLaunchKernelGGL((sumpool2_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (T*)dst, acc, H, W, C, tv));
     return launch_status("sumpool2");
+}
+
+extern "C" int mdm_add(int dtype, void* dst, const void* src, int64_t n, void* stream) {
+    MDM_REQUIRE(n % 8 == 0 && dst && src, "add: n must be a multiple of 8");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (T*)dst, (const T*)src, n / 8));
+    return launch_status("add");
 }
 
 extern "C" int mdm_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int Cp, void* stream) {

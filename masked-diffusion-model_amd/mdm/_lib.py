@@ -47,6 +47,7 @@ _PROTOS = {
     "mdm_silu_bwd": ([vp, vp, vp, i32, i64, vp], i32),
     "mdm_colsum": ([i32, vp, i32, i32, i32, vp, i32, i32, vp, vp], i32),
     "mdm_sumpool2": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "mdm_add": ([i32, vp, vp, i64, vp], i32),
     "mdm_nchw_to_nhwc": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_nhwc_to_nchw": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_draw_timesteps": ([vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),
@@ -101,8 +102,49 @@ def check(rc, what=""):
         raise RuntimeError(f"libmdm_hip {what} failed ({rc}): {load().mdm_last_error().decode()}")
 
 
+class Recording:
+    """A recorded launch sequence: every C-ABI call made while it is active is appended
+    (function, args-without-stream) instead of being executed; `run()` replays the list on
+    the current stream.  All kernel entry points take the stream as their LAST argument."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []      # objects (descriptors, tensors) that must outlive the list
+
+    def __enter__(self):
+        global _recording
+        self._prev = _recording
+        _recording = self
+        return self
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = self._prev
+        return False
+
+    def run(self, st=None):
+        st = stream() if st is None else st
+        for name, fn, args in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                check(rc, name)
+
+    def extend(self, other):
+        self.calls.extend(other.calls)
+        self.keep.extend(other.keep)
+
+
+_recording = None
+
+
 def call(name, *args):
-    check(getattr(load(), name)(*args), name)
+    """Call a kernel entry point (last positional argument = stream) or record it."""
+    fn = getattr(load(), name)
+    if _recording is not None:
+        _recording.calls.append((name, fn, args[:-1]))
+        _recording.keep.append(args)
+        return
+    check(fn(*args), name)
 
 
 def ptr(t):
@@ -114,6 +156,8 @@ def ptr(t):
 
 def stream():
     """The HIP stream kernels are launched on: torch's current stream of the current device."""
+    if _recording is not None:
+        return None        # filled in at replay time
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -122,6 +166,7 @@ def torch_dtype(dt):
 
 
 def gemm(**kw):
+    """Fill a descriptor from keyword fields (tensors become device pointers) and launch / record it."""
     d = GemmDesc()
     d.alpha = 1.0
     d.batch = 1
@@ -129,5 +174,7 @@ def gemm(**kw):
         if isinstance(v, torch.Tensor):
             v = v.data_ptr()
         setattr(d, k, v)
+    if _recording is not None:
+        _recording.keep.append((d, kw))
     call("mdm_gemm", C.byref(d), stream())
     return d

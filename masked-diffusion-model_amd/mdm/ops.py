@@ -138,6 +138,10 @@ def nhwc_to_nchw(dt, x, y, N, C, H, W, Cp):
     call("mdm_nhwc_to_nchw", dt, ptr(x), ptr(y), N, C, H, W, Cp, stream())
 
 
+def add_(dt, dst, src):
+    call("mdm_add", dt, ptr(dst), ptr(src), dst.numel(), stream())
+
+
 def fill(t, v):
     call("mdm_fill_f32", ptr(t), float(v), t.numel(), stream())
 

@@ -1,0 +1,535 @@
+"""The unet6 U-Net on libmdm_hip.so: parameter store, static launch plan, hipGraph replay.
+
+Mirrors reference code/models/unet/unet6.py `UNet` (:365-506) behind the same call
+contract `model(x[N,C,H,W], t[N]).sample` and the same state_dict key
+grammar, but nothing here is an nn.Module: parameters live in ONE flat fp32 buffer
+(plus flat grad / bf16-shadow buffers) and a forward or backward pass is a recorded
+list of C-ABI launches over statically allocated NHWC activations.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib, ops
+from ._lib import BF16, F32
+
+
+def unet6_config(image_size, in_channels=3, out_channels=3):
+    """Presets of reference models_Unet.py:132-171 (`Model('unet6', C, H, W, out_C)`)."""
+    if image_size in (32, 64):
+        mult, attn = [1, 2, 2, 2], [False, False, True, False]
+    elif image_size in (128, 256):
+        mult, attn = [1, 1, 2, 2, 4, 4], [False, False, False, False, True, False]
+    else:
+        raise NotImplementedError("model selection error")
+    return dict(in_channels=in_channels, hid_channels=128, out_channels=out_channels, ch_multipliers=mult,
+                num_res_blocks=2, apply_attn=attn)
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+# --------------------------------------------------------------------------- #
+class Act:
+    """A statically allocated NHWC activation and (lazily) its gradient."""
+
+    def __init__(self, name, N, H, W, C, needs_grad=True):
+        self.name, self.N, self.H, self.W, self.C = name, N, H, W, C
+        self.data = None
+        self.grad = None
+        self.grad_written = False
+        self.needs_grad = needs_grad
+
+    @property
+    def P(self):
+        return self.H * self.W
+
+
+class ParamStore:
+    """Flat fp32 master / grad buffers with named views.
+
+    Internal layouts: conv weight `[tap][Cout_p][Cin_p]` (reference OIHW, unet6.py:196-199),
+    linear `[out][in]` (unet6.py:157), vectors as is; `_p` = padded to a multiple of 8.
+    All `fc.weight` (and `fc.bias`) are stored back to back so the 22 time-embedding
+    projections of unet6.py:350,359 run as ONE contraction.
+    """
+
+    def __init__(self):
+        self.entries = OrderedDict()     # name -> SimpleNamespace(off, ishape, rshape, kind)
+        self.size = 0
+        self.P = self.G = self.Pb = None
+
+    def declare(self, name, kind, rshape, ishape):
+        assert name not in self.entries, name
+        n = 1
+        for d in ishape:
+            n *= d
+        self.entries[name] = SimpleNamespace(off=self.size, n=n, ishape=tuple(ishape), rshape=tuple(rshape), kind=kind)
+        self.size += (n + 7) // 8 * 8          # keep every view 32-byte aligned
+
+    def allocate(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.P = torch.zeros(self.size, device=device, dtype=torch.float32)
+        self.G = torch.zeros(self.size, device=device, dtype=torch.float32)
+        self.Pb = torch.zeros(self.size, device=device, dtype=torch.bfloat16) if dtype == BF16 else None
+
+    def f(self, name):          # fp32 master view
+        e = self.entries[name]
+        return self.P[e.off:e.off + e.n].view(e.ishape)
+
+    def g(self, name):          # fp32 gradient view
+        e = self.entries[name]
+        return self.G[e.off:e.off + e.n].view(e.ishape)
+
+    def w(self, name):          # view the contraction kernels read (bf16 shadow or the master itself)
+        if self.dtype == F32:
+            return self.f(name)
+        e = self.entries[name]
+        return self.Pb[e.off:e.off + e.n].view(e.ishape)
+
+    def sync_shadow(self):
+        if self.Pb is not None:
+            ops.cast_bf16(self.P, self.Pb)
+
+    # -- reference state_dict interchange
+    def to_internal(self, name, t):
+        e = self.entries[name]
+        t = t.detach().to(torch.float32)
+        assert tuple(t.shape) == e.rshape, (name, tuple(t.shape), e.rshape)
+        if e.kind == "conv":
+            o, i, kh, kw = e.rshape
+            out = torch.zeros(e.ishape, dtype=torch.float32)
+            out[:, :o, :i] = t.permute(2, 3, 0, 1).reshape(kh * kw, o, i)
+            return out
+        if e.kind == "vecpad":
+            out = torch.zeros(e.ishape, dtype=torch.float32)
+            out[:e.rshape[0]] = t
+            return out
+        return t.reshape(e.ishape)
+
+    def to_reference(self, name, t):
+        e = self.entries[name]
+        t = t.detach().to("cpu", torch.float32)
+        if e.kind == "conv":
+            o, i, kh, kw = e.rshape
+            return t[:, :o, :i].reshape(kh, kw, o, i).permute(2, 3, 0, 1).contiguous()
+        if e.kind == "vecpad":
+            return t[:e.rshape[0]].clone()
+        return t.reshape(e.rshape).clone()
+
+    def load_state_dict(self, sd):
+        missing = [k for k in self.entries if k not in sd]
+        extra = [k for k in sd if k not in self.entries]
+        if missing or extra:
+            raise KeyError(f"state_dict mismatch: missing={missing[:4]} unexpected={extra[:4]}")
+        host = torch.zeros(self.size, dtype=torch.float32)
+        for k, e in self.entries.items():
+            host[e.off:e.off + e.n] = self.to_internal(k, sd[k]).reshape(-1)
+        self.P.copy_(host)
+        self.sync_shadow()
+
+    def state_dict(self, order=None, src=None):
+        src = self.P if src is None else src
+        host = src.detach().to("cpu")
+        keys = order or list(self.entries)
+        return OrderedDict((k, self.to_reference(k, host[self.entries[k].off:self.entries[k].off + self.entries[k].n]
+                                                 .view(self.entries[k].ishape))) for k in keys)
+
+    def grad_dict(self):
+        return self.state_dict(src=self.G)
+
+
+# --------------------------------------------------------------------------- #
+class _Conv:
+    def __init__(self, net, name, geom, src0, src1, out, fc_slot=None, resid=None):
+        self.net, self.name, self.g, self.src0, self.src1, self.out = net, name, geom, src0, src1, out
+        self.fc_slot, self.resid = fc_slot, resid
+
+    def declare(self, st):
+        g = self.g
+        rs = self.rshape
+        st.declare(self.name + ".weight", "conv", rs, (g.taps, g.Cout, g.Cin))
+        st.declare(self.name + ".bias", "vecpad", (rs[0],), (g.Cout,))
+
+    def fwd(self):
+        n, st, g = self.net, self.net.store, self.g
+        rv, ld = (None, 0)
+        if self.fc_slot is not None:
+            rv, ld = n.T_all[:, self.fc_slot:], n.fc_total
+        ops.conv_fwd(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
+                     st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
+                     resid=self.resid.data if self.resid else None)
+
+    def bwd(self):
+        n, st, g = self.net, self.net.store, self.g
+        assert self.out.grad_written, self.name
+        dy = self.out.grad
+        r = self.resid
+        if r is not None and r.needs_grad:       # y = conv(..) + resid  (unet6.py:333, 362)
+            if not r.grad_written:
+                r.grad, r.grad_written = dy, True      # alias: dy is dead after this op, later ops += into it
+            else:
+                ops.add_(n.dt, r.grad, dy)
+        per, ld = (None, 0)
+        if self.fc_slot is not None:
+            per, ld = n.dT_all[:, self.fc_slot:], n.fc_total
+        ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
+        ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"))
+        s0, s1 = self.src0, self.src1
+        if not s0.needs_grad:
+            return
+        if g.ups:
+            tmp = n.scratch(g.N * g.VH * g.VW * g.Cin)
+            ops.conv_dgrad(n.dt, g, dy, st.w(self.name + ".weight"), tmp, 0)
+            g0, a0 = n.grad_for_write(s0)
+            ops.sumpool2(n.dt, tmp, g0, a0, g.N, g.IH, g.IW, g.Cin)
+        else:
+            g0, a0 = n.grad_for_write(s0)
+            g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
+            ops.conv_dgrad(n.dt, g, dy, st.w(self.name + ".weight"), g0, a0, g1, a1)
+
+
+class _Norm:
+    def __init__(self, net, name, src0, src1, out, silu):
+        self.net, self.name, self.src0, self.src1, self.out, self.silu = net, name, src0, src1, out, silu
+
+    def declare(self, st):
+        c = self.out.C
+        st.declare(self.name + ".weight", "vec", (c,), (c,))
+        st.declare(self.name + ".bias", "vec", (c,), (c,))
+
+    def fwd(self):
+        n, st = self.net, self.net.store
+        s0, s1 = self.src0, self.src1
+        self.stats = n.alloc((s0.N, 32, 2), torch.float32)
+        ops.groupnorm_fwd(n.dt, s0.data, s0.C, s1.data if s1 else None, s1.C if s1 else 0, s0.N, s0.P,
+                          st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, self.out.data, self.stats, n.gn_ws)
+
+    def bwd(self):
+        n, st = self.net, self.net.store
+        s0, s1 = self.src0, self.src1
+        assert self.out.grad_written, self.name
+        g0, a0 = n.grad_for_write(s0)
+        g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
+        ops.groupnorm_bwd(n.dt, s0.data, s0.C, s1.data if s1 else None, s1.C if s1 else 0, s0.N, s0.P,
+                          st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, self.out.grad, self.stats,
+                          g0, a0, g1, a1, st.g(self.name + ".weight"), st.g(self.name + ".bias"), n.gn_ws)
+
+
+class _AttnCore:
+    """softmax(q k^T / sqrt(C)) v over L = H*W tokens, one head (unet6.py:316-324)."""
+
+    def __init__(self, net, qkv, out):
+        self.net, self.qkv, self.out = net, qkv, out
+
+    def declare(self, st):
+        pass
+
+    def fwd(self):
+        n, q, o = self.net, self.qkv, self.out
+        N, L, C = q.N, q.P, o.C
+        self.S = n.alloc((N, L, L), n.tdtype)
+        d = q.data.view(N, L, 3 * C)
+        sc = 1.0 / math.sqrt(C)
+        ops.matmul(n.dt, 0, L, L, C, d, 3 * C, d[:, :, C:], 3 * C, self.S, L, batch=N, sA=L * 3 * C, sB=L * 3 * C, sD=L * L, alpha=sc)
+        ops.softmax_fwd(n.dt, self.S, N * L, L)
+        ops.matmul(n.dt, 1, L, C, L, self.S, L, d[:, :, 2 * C:], 3 * C, o.data, C, batch=N, sA=L * L, sB=L * 3 * C, sD=L * C)
+
+    def bwd(self):
+        n, q, o = self.net, self.qkv, self.out
+        N, L, C = q.N, q.P, o.C
+        assert o.grad_written
+        dqkv, acc = n.grad_for_write(q)
+        assert acc == 0
+        d = q.data.view(N, L, 3 * C)
+        g = dqkv.view(N, L, 3 * C)
+        do = o.grad
+        sc = 1.0 / math.sqrt(C)
+        dP = n.alloc((N, L, L), n.tdtype)
+        s3, sl, sc_ = L * 3 * C, L * L, L * C
+        ops.matmul(n.dt, 2, L, C, L, self.S, L, do, C, g[:, :, 2 * C:], 3 * C, batch=N, sA=sl, sB=sc_, sD=s3)           # dV = P^T dO
+        ops.matmul(n.dt, 0, L, L, C, do, C, d[:, :, 2 * C:], 3 * C, dP, L, batch=N, sA=sc_, sB=s3, sD=sl)               # dP = dO V^T
+        ops.softmax_bwd(n.dt, self.S, dP, N * L, L)                                                                     # dS
+        ops.matmul(n.dt, 1, L, C, L, dP, L, d[:, :, C:], 3 * C, g, 3 * C, batch=N, sA=sl, sB=s3, sD=s3, alpha=sc)        # dQ = dS K
+        ops.matmul(n.dt, 2, L, C, L, dP, L, d, 3 * C, g[:, :, C:], 3 * C, batch=N, sA=sl, sB=s3, sD=s3, alpha=sc)        # dK = dS^T Q
+
+
+class _Temb:
+    """Sinusoidal embedding -> 2-layer MLP -> SiLU -> all 22 per-block projections in one
+    contraction (unet6.py:18-34, 395-399, 350, 359).  fp32 throughout (rows = batch only)."""
+
+    def __init__(self, net, hid, temb, fc_total):
+        self.net, self.hid, self.temb, self.fc_total = net, hid, temb, fc_total
+
+    def declare(self, st):
+        st.declare("embed.0.weight", "lin", (self.temb, self.hid), (self.temb, self.hid))
+        st.declare("embed.0.bias", "vec", (self.temb,), (self.temb,))
+        st.declare("embed.2.weight", "lin", (self.temb, self.temb), (self.temb, self.temb))
+        st.declare("embed.2.bias", "vec", (self.temb,), (self.temb,))
+
+    def fwd(self):
+        n, st = self.net, self.net.store
+        N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
+        f = lambda *s: n.alloc(s, torch.float32)
+        self.e, self.h1, self.a1, self.tm, self.st_ = f(N, hid), f(N, te), f(N, te), f(N, te), f(N, te)
+        ops.timestep_embedding(n.t_in, N, hid, self.e)
+        ops.matmul(F32, 0, N, te, hid, self.e, hid, st.f("embed.0.weight"), hid, self.h1, te, bias=st.f("embed.0.bias"))
+        ops.silu_fwd(self.h1, self.a1, N * te)
+        ops.matmul(F32, 0, N, te, te, self.a1, te, st.f("embed.2.weight"), te, self.tm, te, bias=st.f("embed.2.bias"))
+        ops.silu_fwd(self.tm, self.st_, N * te)
+        ops.matmul(F32, 0, N, ft, te, self.st_, te, n.fc_w, te, n.T_all, ft, bias=n.fc_b)
+
+    def bwd(self):
+        n, st = self.net, self.net.store
+        N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
+        f = lambda *s: n.alloc(s, torch.float32)
+        d_st, d_tm, d_a1, d_h1 = f(N, te), f(N, te), f(N, te), f(N, te)
+        ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1)
+        ops.colsum(F32, n.dT_all, 1, N, ft, dbias=n.fc_gb)
+        ops.matmul(F32, 1, N, te, ft, n.dT_all, ft, n.fc_w, te, d_st, te)
+        ops.silu_bwd(self.tm, d_st, d_tm, 0, N * te)
+        ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g("embed.2.weight"), te, acc=1, out_f32=1)
+        ops.colsum(F32, d_tm, 1, N, te, dbias=st.g("embed.2.bias"))
+        ops.matmul(F32, 1, N, te, te, d_tm, te, st.f("embed.2.weight"), te, d_a1, te)
+        ops.silu_bwd(self.h1, d_a1, d_h1, 0, N * te)
+        ops.matmul(F32, 2, te, hid, N, d_h1, te, self.e, hid, st.g("embed.0.weight"), hid, acc=1, out_f32=1)
+        ops.colsum(F32, d_h1, 1, N, te, dbias=st.g("embed.0.bias"))
+
+
+# --------------------------------------------------------------------------- #
+class UNet:
+    """HIP unet6.  `UNet(cfg, N, H, W, dtype=BF16)`; `model(x, t).sample`; `forward_plan` /
+    `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
+
+    def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mdm.UNet needs a GPU and libmdm_hip.so; there is no CPU fallback")
+        _lib.load()
+        self.cfg = dict(cfg)
+        self.N, self.H, self.W = N, H, W
+        self.dt = dtype
+        self.tdtype = _lib.torch_dtype(dtype)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.training = True
+        self._bufs = []
+        self._scratch = None
+        self._scratch_n = 0
+        self.store = ParamStore()
+        self._build_specs()
+        self._declare_params()
+        self.store.allocate(self.device, dtype)
+        self._materialize()
+        if params is None:
+            from .init import xavier_like_params
+            params = xavier_like_params(self.reference_shapes(), seed)
+        self.load_state_dict(params)
+        self.forward_plan = self._record(self._emit_fwd)
+        self.backward_plan = self._record(self._emit_bwd)
+        self._graph_fwd = None
+
+    # ---- construction ---------------------------------------------------------
+    def _act(self, name, H, W, C, needs_grad=True):
+        a = Act(name, self.N, H, W, C, needs_grad)
+        self.acts.append(a)
+        return a
+
+    def _build_specs(self):
+        cfg, N = self.cfg, self.N
+        cin, hid, cout = cfg["in_channels"], cfg["hid_channels"], cfg["out_channels"]
+        mult, nres, attn = cfg["ch_multipliers"], cfg["num_res_blocks"], cfg["apply_attn"]
+        if isinstance(attn, bool):
+            attn = [attn] * len(mult)
+        temb = cfg.get("time_embedding_dim") or 4 * hid
+        levels = len(mult)
+        assert hid % 32 == 0, "GroupNorm(32) needs hid_channels % 32 == 0"
+        assert self.H % (1 << (levels - 1)) == 0 and self.W % (1 << (levels - 1)) == 0
+        self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, _pad8(cin), _pad8(cout)
+        self.acts, self.specs, self.fc_slots = [], [], OrderedDict()
+        self.ref_order = []
+        G = ops.ConvGeom
+
+        def conv(name, src0, src1, Cout, k=3, stride=1, ups=0, fc=None, resid=None, rshape=None):
+            H_, W_ = src0.H, src0.W
+            pads = (1, 1, 1, 1) if k == 3 and stride == 1 else (0, 0, 1, 1) if k == 3 else (0, 0, 0, 0)
+            g = G(N=N, IH=H_, IW=W_, C0=src0.C, C1=src1.C if src1 else 0, Cout=Cout, KH=k, KW=k, stride=stride,
+                  pad_t=pads[0], pad_l=pads[1], pad_b=pads[2], pad_r=pads[3], ups=ups)
+            out = self._act(name, g.OH, g.OW, Cout)
+            c = _Conv(self, name, g, src0, src1, out, fc_slot=fc, resid=resid)
+            c.rshape = rshape or (Cout, g.Cin, k, k)
+            self.specs.append(c)
+            return out
+
+        def norm(name, src0, src1, silu):
+            out = self._act(name, src0.H, src0.W, src0.C + (src1.C if src1 else 0))
+            self.specs.append(_Norm(self, name, src0, src1, out, silu))
+            return out
+
+        def res(pre, x0, x1, Cout):                       # ResidualBlock (unet6.py:336-362)
+            Cin = x0.C + (x1.C if x1 else 0)
+            slot = self.fc_total
+            self.fc_slots[pre + ".fc"] = (slot, Cout)
+            self.fc_total += Cout
+            skip = conv(pre + ".skip", x0, x1, Cout, k=1) if Cin != Cout else x0
+            a = norm(pre + ".norm1", x0, x1, True)
+            h = conv(pre + ".conv1", a, None, Cout, fc=slot)
+            b = norm(pre + ".norm2", h, None, True)
+            return conv(pre + ".conv2", b, None, Cout, resid=skip)
+
+        def att(pre, x):                                  # AttentionBlock (unet6.py:296-333)
+            C = x.C
+            nrm = norm(pre + ".norm", x, None, False)
+            qkv = conv(pre + ".project_in", nrm, None, 3 * C, k=1)
+            o = self._act(pre + ".attn", x.H, x.W, C)
+            self.specs.append(_AttnCore(self, qkv, o))
+            return conv(pre + ".project_out", o, None, C, k=1, resid=x)
+
+        def block(pre, x0, x1, Cout, a):
+            if a:
+                return att(pre + ".1", res(pre + ".0", x0, x1, Cout))
+            return res(pre, x0, x1, Cout)
+
+        self.fc_total = 0
+        self.temb_dim = temb
+        self.temb_spec = _Temb(self, hid, temb, 0)
+        self.specs.append(self.temb_spec)
+        self.x_in = self._act("x_in", self.H, self.W, self.cin_p, needs_grad=False)
+        hs = [conv("in_conv", self.x_in, None, hid, rshape=(hid, cin, 3, 3))]
+        for l in range(levels):                           # unet6.py:484-491
+            cur = mult[l] * hid
+            for j in range(nres):
+                hs.append(block(f"downsamples.level_{l}.{j}", hs[-1], None, cur, attn[l]))
+            if l != levels - 1:
+                hs.append(conv(f"downsamples.level_{l}.{nres}.1", hs[-1], None, cur, stride=2))
+        h = res("middle.0", hs[-1], None, hs[-1].C)       # unet6.py:494
+        h = att("middle.1", h)
+        h = res("middle.2", h, None, h.C)
+        for l in range(levels - 1, -1, -1):               # unet6.py:497-503
+            cur = mult[l] * hid
+            for j in range(nres + 1):
+                h = block(f"upsamples.level_{l}.{j}", h, hs.pop(), cur, attn[l])
+            if l != 0:
+                h = conv(f"upsamples.level_{l}.{nres + 1}.1", h, None, cur, ups=1)
+        assert not hs
+        h = norm("out_conv.0", h, None, True)             # unet6.py:505
+        self.y_out = conv("out_conv.2", h, None, self.cout_p, rshape=(cout, hid, 3, 3))
+        self.temb_spec.fc_total = self.fc_total
+
+    def _declare_params(self):
+        st = self.store
+        self.temb_spec.declare(st)
+        te = self.temb_dim
+        for name, (slot, co) in self.fc_slots.items():
+            st.declare(name + ".weight", "lin", (co, te), (co, te))
+        for name, (slot, co) in self.fc_slots.items():
+            st.declare(name + ".bias", "vec", (co,), (co,))
+        for s in self.specs[1:]:
+            s.declare(st)
+
+    def reference_shapes(self):
+        return OrderedDict((k, e.rshape) for k, e in self.store.entries.items())
+
+    def alloc(self, shape, dtype):
+        t = torch.zeros(tuple(shape), device=self.device, dtype=dtype)
+        self._bufs.append(t)
+        return t
+
+    def scratch(self, numel):
+        if self._scratch is None or self._scratch_n < numel:
+            self._scratch = self.alloc((numel,), self.tdtype)
+            self._scratch_n = numel
+        return self._scratch
+
+    def grad_for_write(self, act):
+        if act.grad is None:
+            act.grad = self.alloc((act.N, act.H, act.W, act.C), self.tdtype)
+        acc = 1 if act.grad_written else 0
+        act.grad_written = True
+        return act.grad, acc
+
+    def _materialize(self):
+        st = self.store
+        for a in self.acts:
+            a.data = self.alloc((a.N, a.H, a.W, a.C), self.tdtype)
+        names = list(self.fc_slots)
+        e0, e1 = st.entries[names[0] + ".weight"], st.entries[names[0] + ".bias"]
+        ft, te = self.fc_total, self.temb_dim
+        assert all(co % 8 == 0 for _, co in self.fc_slots.values())
+        self.fc_w, self.fc_gw = st.P[e0.off:e0.off + ft * te].view(ft, te), st.G[e0.off:e0.off + ft * te].view(ft, te)
+        self.fc_b, self.fc_gb = st.P[e1.off:e1.off + ft], st.G[e1.off:e1.off + ft]
+        self.T_all = self.alloc((self.N, ft), torch.float32)
+        self.dT_all = self.alloc((self.N, ft), torch.float32)
+        self.t_in = self.alloc((self.N,), torch.float32)
+        self.gn_ws = self.alloc((self.N, 32, 2), torch.float32)
+        self.x_nchw = self.alloc((self.N, self.cin, self.H, self.W), torch.float32)
+        self.y_nchw = self.alloc((self.N, self.cout, self.H, self.W), torch.float32)
+
+    def _record(self, emit):
+        with _lib.Recording() as rec:
+            emit()
+        return rec
+
+    def _emit_fwd(self):
+        for s in self.specs:
+            s.fwd()
+
+    def _emit_bwd(self):
+        """Backward of everything after `y_out.grad` has been written by the caller's loss kernel."""
+        self.y_out.grad = self.alloc((self.N, self.H, self.W, self.cout_p), self.tdtype)
+        self.y_out.grad_written = True
+        for s in reversed(self.specs):
+            s.bwd()
+
+    # ---- reference-compatible surface -------------------------------------------
+    def load_state_dict(self, sd):
+        self.store.load_state_dict(sd)
+
+    def state_dict(self):
+        return self.store.state_dict()
+
+    def parameters(self):
+        return [self.store.P]
+
+    def num_parameters(self):
+        n = 0
+        for e in self.store.entries.values():
+            k = 1
+            for d in e.rshape:
+                k *= d
+            n += k
+        return n
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def zero_grad(self):
+        self.store.G.zero_()
+
+    def run_forward(self):
+        """x_in (NHWC, padded) and t_in must already hold the inputs."""
+        self.forward_plan.run()
+
+    def run_backward(self):
+        """y_out.grad must hold dL/dpred; parameter grads are ACCUMULATED into store.G."""
+        self.backward_plan.run()
+
+    def forward(self, x, t):
+        """x: [N,C,H,W] fp32 (any device), t: [N] -> object with `.sample` [N,C_out,H,W] fp32 on the GPU
+        (reference contract: trainer_masked_mean_shift.py:140, sampler.py:145)."""
+        assert tuple(x.shape) == (self.N, self.cin, self.H, self.W), (tuple(x.shape), (self.N, self.cin, self.H, self.W))
+        self.x_nchw.copy_(x.to(torch.float32), non_blocking=True)
+        self.t_in.copy_(t.reshape(-1).to(torch.float32), non_blocking=True)
+        ops.nchw_to_nhwc(self.dt, self.x_nchw, self.x_in.data, self.N, self.cin, self.H, self.W, self.cin_p)
+        self.run_forward()
+        ops.nhwc_to_nchw(self.dt, self.y_out.data, self.y_nchw, self.N, self.cout, self.H, self.W, self.cout_p)
+        return SimpleNamespace(sample=self.y_nchw.clone())
+
+    __call__ = forward
