@@ -162,7 +162,8 @@ int mdm_index_mask(const double* count, int count_stride, const uint64_t* rng, i
 /* Shift (scheduler.py:612-732) + perturb_shift (:757-766):  s = z * ratio,  x_in = x_t + s.
  *   z: [N][zc][zhw] draws (replay) or NULL (device Philox normal(mean,1) / uniform(-1,1) per `kind`);
  *   kind: 0 non_shift, 1 '1-d_constant' (zc=1,zhw=1,uniform), 2 '3-d_constant' (zc=3,zhw=1,uniform),
- *         3 'noise_reduction' (zc=1,zhw=HW,normal), 4 'noise_with_perturbation' (zc=3,zhw=HW,normal);
+ *         3 'noise_reduction' (zc=1,zhw=HW,normal), 4 'noise_with_perturbation' (zc=3,zhw=HW,normal),
+ *         5 'noise_std_reduction' (zc=3,zhw=HW; s = N(noise_mean, ratio_n); a replayed z IS the shift);
  *   ratio: [N] double; per_column != 0 reproduces the reference's N==W broadcast (ratio indexed by column w);
  *   outputs: s [N][C][HW] (may be NULL), x_in fp32 NCHW (may be NULL), x_in_nhwc (dtype, Cp channels; may be NULL). */
 int mdm_shift(const float* x_t, const float* z, const double* ratio, const uint64_t* rng, int rng_stream,

@@ -33,7 +33,16 @@ __device__ __forceinline__ const T* src_ptr(const T* s0, const T* s1, int C0, in
 
 constexpr int GN_SLAB = 8;    // passes per workgroup: a workgroup covers GN_SLAB * pix_per_pass pixels of one image
 
-// ---- forward pass 1: per (image, group) sum and sum of squares -> ws[N][G][2]
+// ---- forward pass 1: per (image, group) SHIFTED sums  sum(x-K), sum((x-K)^2) -> ws[N][G][2]
+// K = the group's first element of that image.  Shifting removes the cancellation of
+// E[x^2]-mean^2 and makes constant feature maps (a fully degraded, all-zero input image gives
+// them) come out with variance exactly 0 and mean exactly K, as the reference's two-pass
+// group_norm does.
+template <typename T>
+__device__ __forceinline__ float gn_pivot(const T* s0, const T* s1, int C0, int C1, int64_t img_pix0, int grp, int cpg) {
+    return Elem<T>::ld(src_ptr(s0, s1, C0, C1, img_pix0, grp * cpg));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, float* ws) {
     const GnGeom g = gn_geom(C0, C1, G);
@@ -43,14 +52,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* s0, int C0, cons
     __syncthreads();
     if (t < g.lanes_used) {
         const int v = t % g.VPP, c = v * 8;
-        float s[8] = {}, q[8] = {};
+        float s[8] = {}, q[8] = {}, K[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, (c + e) / g.cpg, g.cpg);
         const int p_beg = blockIdx.x * GN_SLAB * g.pix_per_pass;
         const int p_end = min(P, p_beg + GN_SLAB * g.pix_per_pass);
         for (int p = p_beg + t / g.VPP; p < p_end; p += g.pix_per_pass) {
             float8 x = load8(src_ptr(s0, s1, C0, C1, (int64_t)img * P + p, c));
             float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += xv[e]; q[e] = fmaf(xv[e], xv[e], q[e]); }
+            for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; s[e] += dlt; q[e] = fmaf(dlt, dlt, q[e]); }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -63,12 +74,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* s0, int C0, cons
     if (t < 2 * G) atomicAdd(&ws[(int64_t)img * G * 2 + t], red[t]);
 }
 
-__global__ void gn_finalize_kernel(const float* ws, float* stats, int n, float inv_cnt, float eps) {
+template <typename T>
+__global__ void gn_finalize_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, const float* ws, float* stats,
+                                   int n, float inv_cnt, float eps) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float mean = ws[2 * i] * inv_cnt;
-    float var = fmaxf(ws[2 * i + 1] * inv_cnt - mean * mean, 0.f);
-    stats[2 * i] = mean;
+    int img = i / G, grp = i - img * G;
+    float K = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, grp, (C0 + C1) / G);
+    float md = ws[2 * i] * inv_cnt;
+    float var = fmaxf(ws[2 * i + 1] * inv_cnt - md * md, 0.f);
+    stats[2 * i] = K + md;
     stats[2 * i + 1] = rsqrtf(var + eps);
 }
 
@@ -332,6 +347,11 @@ __global__ void silu_bwd_kernel(const float* x, const float* dy, float* dx, int 
     }
 }
 
+__global__ void zero_f32_kernel(float* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 static inline int stream_grid(int64_t work_items) {
     int64_t b = (work_items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -361,14 +381,15 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
                                  float* ws, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    MDM_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 2 * N * G, s));
+    // a kernel, not hipMemsetAsync: the call sits inside captured hipGraphs
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(2 * N * G, 256)), dim3(256), 0, s, ws, 2 * N * G);
     const int C = C0 + C1, ppp = (256 / (C / 8)) < 1 ? 1 : 256 / (C / 8);
     dim3 g1(cdiv(P, GN_SLAB * ppp), N);
     const int64_t tv = (int64_t)N * P * (C / 8);
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL((gn_stats_kernel<T>), g1, dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1, P, G, ws);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, s, ws, stats, N * G,
-                           1.f / ((float)(C / G) * (float)P), eps);
+        hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1,
+                           P, G, ws, stats, N * G, 1.f / ((float)(C / G) * (float)P), eps);
         hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1,
                            P, G, gamma, beta, stats, silu, (T*)y, tv);
     });
@@ -381,7 +402,8 @@ extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void
                                  void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    MDM_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 2 * N * G, s));
+    // a kernel, not hipMemsetAsync: the call sits inside captured hipGraphs
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(2 * N * G, 256)), dim3(256), 0, s, ws, 2 * N * G);
     const int C = C0 + C1, ppp = (256 / (C / 8)) < 1 ? 1 : 256 / (C / 8);
     dim3 g1(cdiv(P, GN_SLAB * ppp), N);
     const int64_t tv = (int64_t)N * P * (C / 8);

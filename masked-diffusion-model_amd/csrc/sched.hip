@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* x_t, const floa
                                                     int H, int W, float* s_out, float* x_in, T* x_nhwc, int Cp) {
     const int HW = H * W;
     const int64_t total = (int64_t)N * C * HW;
-    const int zc = (kind == 2 || kind == 4) ? 3 : 1;
-    const int zhw = (kind == 3 || kind == 4) ? HW : 1;
+    const int zc = (kind == 2 || kind == 4 || kind == 5) ? 3 : 1;
+    const int zhw = (kind == 3 || kind == 4 || kind == 5) ? HW : 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int p = (int)(i % HW);
         int64_t r = i / HW;
@@ -132,14 +132,21 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* x_t, const floa
             int64_t zi = ((int64_t)n * zc + czi) * zhw + (zhw == 1 ? 0 : p);
             float zv;
             if (z) zv = z[zi];
-            else {
+            else if (kind == 5) {     // noise_std_reduction: N(noise_mean, ratio_n) (scheduler.py:691-694)
+                uint4 q = philox_at(rng, rng_stream, (uint64_t)zi >> 1);
+                float2 g = box_muller(q.x, q.y);
+                zv = (float)((double)noise_mean + (double)((zi & 1) ? g.y : g.x) * ratio[n]);
+            } else {
                 uint4 q = philox_at(rng, rng_stream, (uint64_t)zi >> 1);
                 if (kind == 1 || kind == 2) zv = u01((zi & 1) ? q.z : q.x) * 2.f - 1.f;
                 else { float2 g = box_muller(q.x, q.y); zv = ((zi & 1) ? g.y : g.x) + noise_mean; }
             }
             // fp32 draw times fp64 ratio, rounded once to fp32 (scheduler.py:625-626, 680, 713, 725)
-            double rt = (per_column && (kind == 3 || kind == 4)) ? ratio[p % W] : ratio[n];
-            sv = (float)((double)zv * rt);
+            if (kind == 5) sv = zv;         // the draw already carries mean and std
+            else {
+                double rt = (per_column && (kind == 3 || kind == 4)) ? ratio[p % W] : ratio[n];
+                sv = (float)((double)zv * rt);
+            }
         }
         float xv = x_t[i] + sv;
         if (s_out) s_out[i] = sv;
@@ -251,9 +258,9 @@ extern "C" int mdm_shift(const float* x_t, const float* z, const double* ratio, 
                          float noise_mean, int per_column, int N, int C, int H, int W, float* s, float* x_in, int dtype,
                          void* x_in_nhwc, int Cp, void* stream) {
     MDM_REQUIRE(x_t && N > 0 && C > 0 && H > 0 && W > 0, "shift: bad shape");
-    MDM_REQUIRE(kind >= 0 && kind <= 4, "shift: bad kind %d", kind);
+    MDM_REQUIRE(kind >= 0 && kind <= 5, "shift: bad kind %d", kind);
     MDM_REQUIRE(kind == 0 || (ratio && (z || rng)), "shift: need ratio and z / rng");
-    MDM_REQUIRE(!(kind == 2 || kind == 4) || C == 3, "shift: kinds 2/4 are hard-wired to 3 channels upstream (D9)");
+    MDM_REQUIRE(!(kind == 2 || kind == 4 || kind == 5) || C == 3, "shift: kinds 2/4 are hard-wired to 3 channels upstream (D9)");
     MDM_REQUIRE(!per_column || N == W, "shift: per_column needs N == W");
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * C * H * W;

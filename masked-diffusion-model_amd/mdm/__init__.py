@@ -6,5 +6,10 @@ Keeps the reference's call surface: Scheduler(args), Sampler(dataset, args, Sche
 dataset_hist).sample(model, timesteps), Trainer(...).train(...), model(x, t).sample.
 """
 from . import _lib  # noqa: F401
-
-__all__ = ["_lib"]
+from ._lib import BF16, F32  # noqa: F401
+from .dist import GradComm  # noqa: F401
+from .optim import EMA, Accelerator, AdamW, get_lr_scheduler  # noqa: F401
+from .sampler import Sampler  # noqa: F401
+from .scheduler import Scheduler  # noqa: F401
+from .trainer import BaseTrainer, Trainer  # noqa: F401
+from .unet import UNet, unet6_config  # noqa: F401

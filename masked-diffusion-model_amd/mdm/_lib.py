@@ -137,6 +137,42 @@ class Recording:
 _recording = None
 
 
+class GraphExec:
+    """A hipGraph instantiated from a Recording (captured on a private stream, replayed on the
+    caller's current stream)."""
+
+    def __init__(self, rec):
+        self.rec = rec                      # keeps descriptors/tensors alive
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        handle = vp()
+        with torch.cuda.stream(side):
+            check(load().mdm_graph_begin(side.cuda_stream), "mdm_graph_begin")
+            try:
+                rec.run(side.cuda_stream)
+            finally:
+                rc = load().mdm_graph_end(side.cuda_stream, C.byref(handle))
+            check(rc, "mdm_graph_end")
+        cur.wait_stream(side)
+        self.handle = handle
+
+    def launch(self, st=None):
+        dbg = os.environ.get("MDM_DBG_SYNC") == "1"
+        if dbg:
+            torch.cuda.synchronize()
+        check(load().mdm_graph_launch(self.handle, stream() if st is None else st), "mdm_graph_launch")
+        if dbg:
+            torch.cuda.synchronize()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().mdm_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def call(name, *args):
     """Call a kernel entry point (last positional argument = stream) or record it."""
     fn = getattr(load(), name)

@@ -1,0 +1,209 @@
+"""Optimizer-side objects the reference's trainers are handed: AdamW, EMA,
+LR schedule, and a thin accelerator -- over the flat parameter buffers of mdm.UNet.
+
+Reference call sites: optimizer `optim.AdamW(model.parameters(), lr=lr)` (main_train_masked.py:134-141,
+torch defaults betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2); EMA `EMAModel(decay=ema_max_decay,
+use_ema_warmup=True, inv_gamma, power)` (:116-131) stepped at trainer_masked_mean_shift.py:170-172;
+LR schedules diffusers `get_*_schedule_with_warmup` (:144-165).  EMAModel and the LR schedules are
+third-party code that is absent from the reference tree: their semantics are implemented from the
+call-site arguments and are NOT oracle-checked ("parity unpinned").
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream
+
+
+class AdamW:
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        st = model.store
+        self.model, self.store = model, st
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, initial_lr=lr)]
+        self.m = torch.zeros_like(st.P)
+        self.v = torch.zeros_like(st.P)
+        self.t = 0
+        self.hp_host = torch.zeros(8).pin_memory()
+        self.hp = torch.zeros(8, device=st.P.device)
+        self.sqnorm = torch.zeros(1, device=st.P.device)
+
+    def hyper(self, ema_decay=0.0, advance=True):
+        """Refresh the 8-float device block read by mdm_adamw_ema (async H2D)."""
+        g = self.param_groups[0]
+        if advance:
+            self.t += 1
+        b1, b2 = g["betas"]
+        self.hp_host[0] = g["lr"]; self.hp_host[1] = b1; self.hp_host[2] = b2; self.hp_host[3] = g["eps"]
+        self.hp_host[4] = g["weight_decay"]
+        self.hp_host[5] = 1 - b1 ** self.t; self.hp_host[6] = 1 - b2 ** self.t; self.hp_host[7] = ema_decay
+        self.hp.copy_(self.hp_host, non_blocking=True)
+
+    def emit_update(self, ema_buf=None, max_norm=1.0, gmul=1.0):
+        """Enqueue (or record) grad-norm + clip + AdamW + EMA + bf16 shadow over the flat buffers."""
+        st = self.store
+        ops.fill(self.sqnorm, 0.0)
+        call("mdm_sqnorm", ptr(st.G), st.size, ptr(self.sqnorm), stream())
+        call("mdm_adamw_ema", ptr(st.P), ptr(st.G), ptr(self.m), ptr(self.v), ptr(ema_buf), ptr(st.Pb), st.size,
+             ptr(self.hp), ptr(self.sqnorm), float(max_norm), float(gmul), stream())
+
+    def step(self, max_norm=0.0):
+        self.hyper()
+        self.emit_update(None, max_norm)
+
+    def zero_grad(self):
+        self.store.G.zero_()
+
+    def grad_norm(self):
+        return float(self.sqnorm.sqrt())
+
+    def state_dict(self):
+        return dict(m=self.m, v=self.v, t=self.t, param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = sd["t"]
+        self.param_groups = sd["param_groups"]
+
+
+class EMA:
+    """Flat-buffer EMA with diffusers' warm-up decay (see module docstring: not oracle-checked)."""
+
+    def __init__(self, model, decay=0.9999, use_ema_warmup=True, inv_gamma=1.0, power=0.75, min_decay=0.0):
+        self.model, self.pstore = model, model.store
+        self.decay, self.use_ema_warmup, self.inv_gamma, self.power, self.min_decay = decay, use_ema_warmup, inv_gamma, power, min_decay
+        self.shadow = model.store.P.clone()
+        self.optimization_step = 0
+        self._backup = None
+
+    def get_decay(self, optimization_step):
+        step = max(0, optimization_step - 1)
+        if step <= 0:
+            return 0.0
+        if self.use_ema_warmup:
+            v = 1 - (1 + step / self.inv_gamma) ** -self.power
+        else:
+            v = (1 + step) / (10 + step)
+        return max(min(v, self.decay), self.min_decay)
+
+    def next_decay(self):
+        self.optimization_step += 1
+        return self.get_decay(self.optimization_step)
+
+    def step(self, parameters=None):
+        d = self.next_decay()
+        self.shadow.sub_((1 - d) * (self.shadow - self.pstore.P))
+
+    def store(self, parameters=None):           # diffusers EMAModel.store / copy_to / restore
+        self._backup = self.pstore.P.clone()
+
+    def copy_to(self, parameters=None):
+        self.pstore.P.copy_(self.shadow)
+        self.pstore.sync_shadow()
+
+    def restore(self, parameters=None):
+        self.pstore.P.copy_(self._backup)
+        self.pstore.sync_shadow()
+        self._backup = None
+
+    def state_dict(self):
+        return dict(shadow=self.shadow, optimization_step=self.optimization_step)
+
+
+class LambdaLR:
+    def __init__(self, optimizer, fn):
+        self.opt, self.fn, self.k = optimizer, fn, 0
+        self.base = optimizer.param_groups[0]["initial_lr"]
+        optimizer.param_groups[0]["lr"] = self.base * fn(0)
+
+    def step(self):
+        self.k += 1
+        self.opt.param_groups[0]["lr"] = self.base * self.fn(self.k)
+
+    def get_last_lr(self):
+        return [self.opt.param_groups[0]["lr"]]
+
+
+def get_lr_scheduler(name, optimizer, num_warmup_steps, num_training_steps, num_cycles=0.5):
+    """'cosine' | 'hard_cosine' | 'constant' | 'linear' with warm-up (main_train_masked.py:144-165)."""
+    w = max(1, num_warmup_steps)
+
+    def warm(k):
+        return k / w if k < num_warmup_steps else None
+    if name == "constant":
+        return LambdaLR(optimizer, lambda k: warm(k) if warm(k) is not None else 1.0)
+    if name == "linear":
+        return LambdaLR(optimizer, lambda k: warm(k) if warm(k) is not None else
+                        max(0.0, (num_training_steps - k) / max(1, num_training_steps - num_warmup_steps)))
+    if name == "cosine":
+        def f(k):
+            if warm(k) is not None:
+                return warm(k)
+            p = (k - num_warmup_steps) / max(1, num_training_steps - num_warmup_steps)
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * num_cycles * 2.0 * p)))
+        return LambdaLR(optimizer, f)
+    if name == "hard_cosine":
+        def f(k):
+            if warm(k) is not None:
+                return warm(k)
+            p = (k - num_warmup_steps) / max(1, num_training_steps - num_warmup_steps)
+            if p >= 1.0:
+                return 0.0
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((num_cycles * p) % 1.0))))
+        return LambdaLR(optimizer, f)
+    raise ValueError(name)
+
+
+class Accelerator:
+    """The subset of `accelerate.Accelerator` the trainers touch, backed by
+    torch.distributed (RCCL on ROCm) when a process group is initialised."""
+
+    def __init__(self, gradient_accumulation_steps=1, mixed_precision="bf16", device=None):
+        import torch.distributed as dist
+        self.dist = dist if dist.is_available() and dist.is_initialized() else None
+        self.num_processes = self.dist.get_world_size() if self.dist else 1
+        self.process_index = self.dist.get_rank() if self.dist else 0
+        self.mixed_precision = mixed_precision
+        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self.sync_gradients = True
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+
+    @property
+    def is_main_process(self):
+        return self.process_index == 0
+
+    is_local_main_process = is_main_process
+
+    def prepare(self, *objs):
+        return objs if len(objs) != 1 else objs[0]
+
+    def accumulate(self, model):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def backward(self, loss):       # the fused train step has already produced the gradients
+        return None
+
+    def clip_grad_norm_(self, params, max_norm):
+        return None
+
+    def wait_for_everyone(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def print(self, *a, **k):
+        if self.is_main_process:
+            print(*a, **k)
+
+    def save_state(self, path, model=None, optimizer=None, ema=None):
+        import os
+        os.makedirs(path, exist_ok=True)
+        if self.is_main_process and model is not None:
+            torch.save(model.state_dict(), os.path.join(path, "unet.pt"))
+            if ema is not None:
+                torch.save(model.store.state_dict(src=ema.shadow), os.path.join(path, "unet_ema.pt"))
+            if optimizer is not None:
+                torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()},
+                           os.path.join(path, "optimizer.pt"))

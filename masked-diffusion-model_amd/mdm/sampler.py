@@ -1,0 +1,142 @@
+"""Reverse (cold-diffusion) sampler on the GPU -- same surface as the reference `Sampler`.
+
+Mirrors reference code/sampler.py: `_get_latent_initial` (:46-83), `sample` (:102-106) and
+`_sample_mean_shift_momentum` (:109-261) for the options that run upstream at HEAD
+(`sampling_mask_dependency` in {independent, dependent_prev}, `momentum_adaptive` in
+{base_sampling, base_momentum}).
+
+What is different from the reference loop (same arithmetic, same RNG order in replay mode):
+  * the whole state stays on the GPU; nothing is copied to the host inside the loop.  The
+    reference's 11 history tensors are optional (`args.sample_history`: True -> returned on
+    the CPU like the reference, "device" -> kept in HBM, False -> skipped, empty list);
+  * per step: one fused shift+perturb kernel, the U-Net forward plan, one fused
+    x0-reconstruction kernel, two degrade kernels and one update kernel.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream
+
+HISTORY_NAMES = ["sample_t", "shift", "shifted", "mask", "shifted_result", "sample_0",
+                 "degraded_mask", "degraded_mask_next", "degraded_t", "difference", "degraded_next_t"]
+
+
+class Sampler:
+    def __init__(self, dataset, args, Scheduler, dataset_hist):
+        self.dataset, self.args, self.Scheduler, self.dataset_hist = dataset, args, Scheduler, dataset_hist
+
+    def _get_latent_initial(self, model=None):
+        """Constant-colour start image per sample, drawn on the host like sampler.py:46-83."""
+        a = self.args
+        if a.mean_area == "image-wise":
+            d = 1
+        elif a.mean_area == "channel-wise":
+            d = 3
+        else:
+            raise UnboundLocalError("mean_area")
+        shape = a.sample_latent_shape.lower()
+        if shape == "data":
+            hshape, edges, cum = self.dataset_hist
+            idx = torch.searchsorted(cum, torch.rand(a.sample_num))
+            idx = np.unravel_index(idx, hshape)
+            mean = torch.empty(a.sample_num, 0)
+            for c in range(d):
+                r = torch.rand(a.sample_num)
+                lo, hi = edges[c][idx[c]], edges[c][idx[c] + 1]
+                mean = torch.cat((mean, ((hi - lo) * r + lo).unsqueeze(-1)), 1)
+        elif shape == "zero":
+            mean = torch.zeros(a.sample_num, d)
+        elif shape == "normal":
+            mean = torch.randn(a.sample_num, d)
+        elif shape == "uniform":
+            mean = torch.empty(a.sample_num, d).uniform_(-1, 1)
+        else:
+            raise IndexError(f"sample_latent_shape={shape!r} does not run upstream")
+        return mean[:, :, None, None].expand(a.sample_num, a.out_channel, a.data_size, a.data_size)
+
+    def sample(self, model, timesteps_used_epoch, interpolation_shift=None):
+        return self._sample_mean_shift_momentum(model, timesteps_used_epoch)
+
+    # ------------------------------------------------------------------------------
+    def _predict(self, model, x_in_nchw, time, fused_nhwc):
+        """-> (pred as NHWC tensor, Cp, dtype) ready for mdm_sampler_x0."""
+        from .unet import UNet
+        if isinstance(model, UNet):
+            if not fused_nhwc:      # x_in was not written into the net by the shift kernel
+                ops.nchw_to_nhwc(model.dt, x_in_nchw, model.x_in.data, model.N, model.cin, model.H, model.W, model.cin_p)
+            model.t_in.copy_(time, non_blocking=True)
+            model.run_forward()
+            return model.y_out.data, model.cout_p, model.dt
+        pred = model(x_in_nchw, time).sample.to(x_in_nchw.device, torch.float32).contiguous()   # any callable model
+        n, c, h, w = pred.shape
+        cp = (c + 7) // 8 * 8
+        nh = torch.empty(n, h, w, cp, device=pred.device)
+        ops.nchw_to_nhwc(_lib.F32, pred, nh, n, c, h, w, cp)
+        return nh, cp, _lib.F32
+
+    def _sample_mean_shift_momentum(self, model, timesteps):
+        from .unet import UNet
+        a, S = self.args, self.Scheduler
+        dev = S.device
+        T = len(timesteps)
+        n, c, hw = a.sample_num, a.out_channel, a.data_size
+        dep, mode = a.sampling_mask_dependency, a.momentum_adaptive
+        if dep not in ("independent", "dependent_prev"):
+            raise UnboundLocalError(f"sampling_mask_dependency={dep!r} does not run upstream (D5)")
+        if mode not in ("base_sampling", "base_momentum"):
+            raise UnboundLocalError(f"momentum_adaptive={mode!r} does not run upstream (D4)")
+        hist_mode = getattr(a, "sample_history", True)
+        fused = isinstance(model, UNet)
+        if fused:
+            assert (model.N, model.H, model.W) == (n, hw, hw), "UNet plan was built for another batch/extent"
+        x_t = self._get_latent_initial(model).to(dev, torch.float32).contiguous()
+        m_next = torch.zeros(n, c, hw, hw, device=dev)
+        hist = None
+        if hist_mode:
+            hist = {k: torch.zeros(T + 1, n, c, hw, hw, device=dev) for k in HISTORY_NAMES}
+        x0_hat = torch.empty_like(x_t)
+        pred_nchw = torch.empty_like(x_t) if hist_mode else None
+        shifted0 = torch.empty_like(x_t) if hist_mode else None
+        diff = torch.zeros_like(x_t)
+        numel = x_t.numel()
+        for i in range(T - 1, -1, -1):
+            slot = T - i
+            S.dev_rng.advance()
+            time = torch.full((n,), float(timesteps[i]), device=dev)
+            if hist_mode:
+                hist["sample_t"][slot].copy_(x_t)
+            nhwc = (model.dt, model.x_in.data, model.cin_p) if fused else None
+            s, x_in = S.shift_and_perturb(time, x_t, want_nhwc=nhwc)                 # sampler.py:142-143
+            pred, cp, pdt = self._predict(model, x_in, time, fused)                  # :145
+            call("mdm_sampler_x0", pdt, ptr(pred), cp, ptr(x_in), ptr(s), n, c, hw, hw, ptr(pred_nchw), ptr(shifted0),
+                 ptr(x0_hat), stream())                                              # :146-152
+            next_t = time - 1 if i > 0 else time                                     # :167-170
+            n_t = S.get_black_area_num_pixels_time(time)
+            n_next = S.get_black_area_num_pixels_time(next_t)
+            if dep == "independent":                                                 # :175-181
+                d_t, m_t, _ = S.degrade_independent_base_sampling(n_t, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area, _stream=3)
+                d_next, m_next, _ = S.degrade_independent_base_sampling(n_next, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area, _stream=4)
+            else:                                                                    # :184-188
+                m_t = None
+                d_t = S.degrade_with_mask(x0_hat, m_next, mean_option=a.mean_option, mean_area=a.mean_area)
+                d_next, m_next, _ = S.degrade_independent_base_sampling(n_next, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area, _stream=4)
+            if hist_mode:
+                hist["shift"][slot].copy_(s); hist["shifted"][slot].copy_(x_in); hist["mask"][slot].copy_(pred_nchw)
+                hist["shifted_result"][slot].copy_(shifted0); hist["sample_0"][slot].copy_(x0_hat)
+                if dep == "independent":
+                    hist["degraded_mask"][slot].copy_(m_t); hist["degraded_mask_next"][slot].copy_(m_next)
+                else:
+                    hist["degraded_mask"][slot].copy_(m_next)
+            if mode == "base_sampling" and i == 0:                                   # :204-205 (break before the writes)
+                break
+            if i > 0 or mode == "base_sampling":                                     # :206-216
+                call("mdm_sampler_update", ptr(d_t), ptr(d_next), ptr(x_t), ptr(diff), int(mode == "base_momentum"), numel, stream())
+            if hist_mode:
+                hist["degraded_next_t"][slot].copy_(d_next); hist["degraded_t"][slot].copy_(d_t); hist["difference"][slot].copy_(diff)
+        out_hist = []
+        if hist_mode:
+            out_hist = [hist[k] if hist_mode == "device" else hist[k].cpu() for k in HISTORY_NAMES]
+        return x0_hat, out_hist

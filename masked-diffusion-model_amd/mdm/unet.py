@@ -306,7 +306,7 @@ class UNet:
     """HIP unet6.  `UNet(cfg, N, H, W, dtype=BF16)`; `model(x, t).sample`; `forward_plan` /
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
-    def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234):
+    def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True):
         if not torch.cuda.is_available():
             raise RuntimeError("mdm.UNet needs a GPU and libmdm_hip.so; there is no CPU fallback")
         _lib.load()
@@ -319,18 +319,30 @@ class UNet:
         self._bufs = []
         self._scratch = None
         self._scratch_n = 0
-        self.store = ParamStore()
+        self.use_graph = use_graph
+        shared = store is not None
+        self.store = store if shared else ParamStore()
         self._build_specs()
-        self._declare_params()
-        self.store.allocate(self.device, dtype)
+        if not shared:
+            self._declare_params()
+            self.store.allocate(self.device, dtype)
+        else:
+            assert store.dtype == dtype, "a shared parameter store must have the same compute dtype"
         self._materialize()
-        if params is None:
-            from .init import xavier_like_params
-            params = xavier_like_params(self.reference_shapes(), seed)
-        self.load_state_dict(params)
+        if not shared:
+            if params is None:
+                from .init import xavier_like_params
+                params = xavier_like_params(self.reference_shapes(), seed)
+            self.load_state_dict(params)
         self.forward_plan = self._record(self._emit_fwd)
         self.backward_plan = self._record(self._emit_bwd)
         self._graph_fwd = None
+
+    def with_batch(self, N):
+        """A second launch plan over the SAME weights for another batch size (e.g. sample_num)."""
+        if N == self.N:
+            return self
+        return UNet(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph)
 
     # ---- construction ---------------------------------------------------------
     def _act(self, name, H, W, C, needs_grad=True):
@@ -427,7 +439,9 @@ class UNet:
             st.declare(name + ".weight", "lin", (co, te), (co, te))
         for name, (slot, co) in self.fc_slots.items():
             st.declare(name + ".bias", "vec", (co,), (co,))
+        self.temb_spec.param_lo = 0
         for s in self.specs[1:]:
+            s.param_lo = st.size
             s.declare(st)
 
     def reference_shapes(self):
@@ -481,8 +495,13 @@ class UNet:
         """Backward of everything after `y_out.grad` has been written by the caller's loss kernel."""
         self.y_out.grad = self.alloc((self.N, self.H, self.W, self.cout_p), self.tdtype)
         self.y_out.grad_written = True
+        # bwd_marks[i] = (#launches emitted so far, lowest flat-buffer offset whose gradient is final):
+        # parameters are declared in forward order, so after the backward of spec j every gradient
+        # at or above spec j's first parameter is complete (mdm.dist.GradComm cuts buckets there).
+        self.bwd_marks = []
         for s in reversed(self.specs):
             s.bwd()
+            self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
 
     # ---- reference-compatible surface -------------------------------------------
     def load_state_dict(self, sd):
@@ -515,7 +534,12 @@ class UNet:
 
     def run_forward(self):
         """x_in (NHWC, padded) and t_in must already hold the inputs."""
-        self.forward_plan.run()
+        if not self.use_graph:
+            self.forward_plan.run()
+            return
+        if self._graph_fwd is None:
+            self._graph_fwd = _lib.GraphExec(self.forward_plan)
+        self._graph_fwd.launch()
 
     def run_backward(self):
         """y_out.grad must hold dL/dpred; parameter grads are ACCUMULATED into store.G."""
