@@ -120,8 +120,10 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* s0, int C0, 
                                                            float* dgamma, float* dbeta) {
     const GnGeom g = gn_geom(C0, C1, G);
     __shared__ float red[2 * 64];
+    extern __shared__ float chan[];          // [2][C]: per-channel dgamma / dbeta partials of this workgroup
     const int t = threadIdx.x, img = blockIdx.y;
     if (t < 2 * G) red[t] = 0.f;
+    for (int i = t; i < 2 * g.C; i += 256) chan[i] = 0.f;
     __syncthreads();
     if (t < g.lanes_used) {
         const int v = t % g.VPP, c = v * 8;
@@ -156,12 +158,16 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* s0, int C0, 
             int grp = (c + e) / g.cpg;
             atomicAdd(&red[2 * grp], a1[e]);
             atomicAdd(&red[2 * grp + 1], a2[e]);
-            atomicAdd(&dgamma[c + e], dg[e]);
-            atomicAdd(&dbeta[c + e], db[e]);
+            atomicAdd(&chan[c + e], dg[e]);                 // LDS atomics: the pixel lanes of one channel meet here
+            atomicAdd(&chan[g.C + c + e], db[e]);
         }
     }
     __syncthreads();
     if (t < 2 * G) atomicAdd(&ws[(int64_t)img * G * 2 + t], red[t]);
+    for (int i = t; i < g.C; i += 256) {                    // one global atomic per channel per workgroup
+        atomicAdd(&dgamma[i], chan[i]);
+        atomicAdd(&dbeta[i], chan[g.C + i]);
+    }
 }
 
 // ---- backward pass 2: dx = rstd * (g*gamma - (s1 + xhat*s2)/cnt)
@@ -408,7 +414,7 @@ extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void
     dim3 g1(cdiv(P, GN_SLAB * ppp), N);
     const int64_t tv = (int64_t)N * P * (C / 8);
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), g1, dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1, P, G, gamma,
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), g1, dim3(256), 2 * C * sizeof(float), s, (const T*)src0, C0, (const T*)src1, C1, P, G, gamma,
                            beta, silu, (const T*)dy, stats, ws, dgamma, dbeta);
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1,
                            C1, P, G, gamma, beta, silu, (const T*)dy, stats, ws, (T*)dst0, acc0, (T*)dst1, acc1, tv);

@@ -110,6 +110,7 @@ class Recording:
     def __init__(self):
         self.calls = []
         self.keep = []      # objects (descriptors, tensors) that must outlive the list
+        self.flops = {}     # call index -> (algorithmic FLOPs, dtype) for contraction launches
 
     def __enter__(self):
         global _recording
@@ -130,8 +131,34 @@ class Recording:
                 check(rc, name)
 
     def extend(self, other):
+        base = len(self.calls)
         self.calls.extend(other.calls)
         self.keep.extend(other.keep)
+        for i, v in other.flops.items():
+            self.flops[base + i] = v
+
+    def run_timed(self, st, pick):
+        """Replay eagerly with a HIP event pair around every launch `pick(index, name)` selects;
+        returns [(index, ms)] (events sit on the launch stream `st`)."""
+        lib = load()
+        pairs = []
+        for i, (name, fn, args) in enumerate(self.calls):
+            if pick(i, name):
+                a, b = vp(), vp()
+                check(lib.mdm_event_create(C.byref(a))); check(lib.mdm_event_create(C.byref(b)))
+                check(lib.mdm_event_record(a, st))
+                check(fn(*args, st), name)
+                check(lib.mdm_event_record(b, st))
+                pairs.append((i, a, b))
+            else:
+                check(fn(*args, st), name)
+        out = []
+        for i, a, b in pairs:
+            ms = f32()
+            check(lib.mdm_event_elapsed_ms(a, b, C.byref(ms)))
+            out.append((i, ms.value))
+            lib.mdm_event_destroy(a); lib.mdm_event_destroy(b)
+        return out
 
 
 _recording = None
@@ -206,11 +233,14 @@ def gemm(**kw):
     d = GemmDesc()
     d.alpha = 1.0
     d.batch = 1
+    flops = kw.pop("_flops", None)
     for k, v in kw.items():
         if isinstance(v, torch.Tensor):
             v = v.data_ptr()
         setattr(d, k, v)
     if _recording is not None:
         _recording.keep.append((d, kw))
+        # algorithmic FLOPs of this launch, keyed by its index in the recording (bench.py roofline)
+        _recording.flops[len(_recording.calls)] = (flops if flops is not None else 2.0 * d.M * d.N * d.K * d.batch, d.dtype)
     call("mdm_gemm", C.byref(d), stream())
     return d

@@ -328,6 +328,7 @@ class UNet:
             self.store.allocate(self.device, dtype)
         else:
             assert store.dtype == dtype, "a shared parameter store must have the same compute dtype"
+        self._set_param_marks()
         self._materialize()
         if not shared:
             if params is None:
@@ -439,10 +440,19 @@ class UNet:
             st.declare(name + ".weight", "lin", (co, te), (co, te))
         for name, (slot, co) in self.fc_slots.items():
             st.declare(name + ".bias", "vec", (co,), (co,))
-        self.temb_spec.param_lo = 0
         for s in self.specs[1:]:
-            s.param_lo = st.size
             s.declare(st)
+
+    def _set_param_marks(self):
+        """spec.param_lo = lowest flat-buffer offset whose gradient is final once the backward of that
+        spec (and of everything after it) has run; parameter-less specs inherit their successor's."""
+        st, lo = self.store, self.store.size
+        for s in reversed(self.specs[1:]):
+            key = getattr(s, "name", None)
+            if key is not None and key + ".weight" in st.entries:
+                lo = st.entries[key + ".weight"].off
+            s.param_lo = lo
+        self.temb_spec.param_lo = 0
 
     def reference_shapes(self):
         return OrderedDict((k, e.rshape) for k, e in self.store.entries.items())
@@ -502,6 +512,38 @@ class UNet:
         for s in reversed(self.specs):
             s.bwd()
             self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
+
+    def census(self):
+        """Leaf-op output elements of ONE forward under the counting rule of SURVEY 8(d) (every
+        reference leaf op writes its output once, no credit for fusion): convs/linears, GroupNorm and
+        SiLU separately, the residual / time-embedding adds, channel concats, x2 upsamples, SamePad
+        copies, and the attention scores, softmax, both einsum outputs and the `.contiguous()` copy."""
+        a_out = 0
+        for s in self.specs:
+            if isinstance(s, _Conv):
+                g, o = s.g, s.out
+                n = o.N * o.H * o.W * o.C
+                a_out += n
+                if s.resid is not None:
+                    a_out += n                              # x + skip (unet6.py:333, 362)
+                if s.fc_slot is not None:
+                    a_out += n + o.N * o.C                  # x += fc(silu(t_emb)) and the fc output
+                if g.ups:
+                    a_out += g.N * g.VH * g.VW * g.Cin      # nn.Upsample output
+                if g.stride == 2:
+                    a_out += g.N * (g.IH + 1) * (g.IW + 1) * g.Cin   # SamePad2d output
+            elif isinstance(s, _Norm):
+                o = s.out
+                n = o.N * o.H * o.W * o.C
+                a_out += n * (2 if s.silu else 1)
+                if s.src1 is not None:
+                    a_out += n                              # torch.cat output (unet6.py:501), read by norm1 and skip
+            elif isinstance(s, _AttnCore):
+                N, L, C = s.qkv.N, s.qkv.P, s.out.C
+                a_out += 2 * N * L * L + 2 * N * L * C
+            elif isinstance(s, _Temb):
+                a_out += self.N * (s.hid + 4 * s.temb)
+        return a_out
 
     # ---- reference-compatible surface -------------------------------------------
     def load_state_dict(self, sd):
