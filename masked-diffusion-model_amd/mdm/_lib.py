@@ -221,6 +221,8 @@ def stream():
     """The HIP stream kernels are launched on: torch's current stream of the current device."""
     if _recording is not None:
         return None        # filled in at replay time
+    if not torch.cuda.is_available():
+        return None        # no device: argument checks still run, any launch then fails loudly in HIP
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -67,7 +67,12 @@ class Scheduler:
         self.updated_ddpm_num_steps = None
         self.ratio_list = None
         self.black_area_pixels = None
-        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if device is not None:
+            self.device = torch.device(device)
+        elif torch.cuda.is_available():
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        else:       # host-only use: schedule tables, timestep lists, gathers (every kernel call needs the GPU)
+            self.device = torch.device("cpu")
         self.rng_mode = getattr(args, "rng_mode", "replay")
         self.reference_quirks = getattr(args, "reference_quirks", True)
         self.dev_rng = DeviceRng(self.device, getattr(args, "seed", 0))

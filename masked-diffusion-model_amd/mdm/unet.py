@@ -306,7 +306,15 @@ class UNet:
     """HIP unet6.  `UNet(cfg, N, H, W, dtype=BF16)`; `model(x, t).sample`; `forward_plan` /
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
-    def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True):
+    def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True,
+                 _dry=False):
+        if _dry:       # shape/parameter bookkeeping only (no device, no kernels): see `param_table`
+            self.cfg, self.N, self.H, self.W, self.dt = dict(cfg), N, H, W, dtype
+            self.store = ParamStore()
+            self._build_specs()
+            self._declare_params()
+            self._set_param_marks()
+            return
         if not torch.cuda.is_available():
             raise RuntimeError("mdm.UNet needs a GPU and libmdm_hip.so; there is no CPU fallback")
         _lib.load()
@@ -338,6 +346,11 @@ class UNet:
         self.forward_plan = self._record(self._emit_fwd)
         self.backward_plan = self._record(self._emit_bwd)
         self._graph_fwd = None
+
+    @staticmethod
+    def param_table(cfg, H=32, W=32):
+        """{reference key: reference shape} in flat-buffer order, computed on the host only."""
+        return UNet(cfg, 1, H, W, _dry=True).reference_shapes()
 
     def with_batch(self, N):
         """A second launch plan over the SAME weights for another batch size (e.g. sample_num)."""

@@ -1,0 +1,232 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol of include/mdm_hip.h, the
+host-side logic (schedule tables, parameter layout, state_dict grammar, bucket planning, EMA/LR
+schedules) and the data-parallel exchange over gloo with 2 processes.  No kernel is launched."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from golden.make_golden import TINY, base_args  # noqa: E402
+
+
+# ------------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    from mdm import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mdm_hip.h")).read()
+    declared = set(re.findall(r"\b(mdm_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mdm_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.mdm_version() == 1
+
+
+def test_descriptor_layout_matches_the_header(tmp_path):
+    from mdm._lib import GemmDesc
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu",'
+                   'sizeof(mdm_gemm_desc),offsetof(mdm_gemm_desc,A),offsetof(mdm_gemm_desc,conv),offsetof(mdm_gemm_desc,src0),'
+                   'offsetof(mdm_gemm_desc,D0),offsetof(mdm_gemm_desc,bias),offsetof(mdm_gemm_desc,dtap));return 0;}\n'
+                   % os.path.join(ROOT, "include", "mdm_hip.h"))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [ctypes.sizeof(GemmDesc), GemmDesc.A.offset, GemmDesc.conv.offset, GemmDesc.src0.offset, GemmDesc.D0.offset,
+            GemmDesc.bias.offset, GemmDesc.dtap.offset]
+    assert got == want
+
+
+def test_errors_come_back_as_exceptions_not_crashes():
+    from mdm import _lib
+    with pytest.raises(RuntimeError, match="bad dtype"):
+        _lib.gemm(dtype=7, layout=0, M=8, N=8, K=8)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        _lib.gemm(dtype=1, layout=0, M=8, N=12, K=8, D0=1, ldd0=8, A=1, B=1, lda=8, ldb=8)
+    with pytest.raises(RuntimeError, match="C <= 8"):
+        _lib.call("mdm_degrade", 1, None, None, None, 1, None, 1, 4, 9, 16, 1, 0, 0.0, None, None, None, None)
+
+
+def test_product_fails_loudly_without_gpu():
+    import mdm
+    if torch.cuda.is_available():
+        pytest.skip("needs a CPU-only box")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mdm.UNet(TINY, N=1, H=16, W=16)
+
+
+# ------------------------------------------------------------------------------- host logic
+@pytest.mark.parametrize("kind", ["linear", "log", "exponential"])
+def test_scheduler_tables_match_reference(golden, kind):
+    import mdm
+    g = golden("schedules")
+    for size in (32, 64):
+        for T in (10, 50, 250, 1000):
+            s = mdm.Scheduler(base_args(data_size=size, ddpm_schedule=kind, ddpm_num_steps=T), device="cpu")
+            assert s.update_ddpm_num_steps(T) == int(g[f"sched_{kind}_{T}_{size}_steps"])
+            assert np.array_equal(s.get_ratio_list().numpy(), g[f"sched_{kind}_{T}_{size}_ratio"])
+            assert np.array_equal(np.asarray(s.get_black_area_num_pixels_all()), g[f"sched_{kind}_{T}_{size}_pixels"])
+
+
+def test_scheduler_timesteps_gather_weights(golden):
+    import mdm
+    g = golden("schedules")
+    for scale in (1, 3):
+        s = mdm.Scheduler(base_args(data_size=32, ddpm_num_steps=50, scheduler_num_scale_timesteps=scale), device="cpu")
+        s.update_ddpm_num_steps(50)
+        for epoch in (0, 3, 5, 8):
+            assert s.get_timesteps_epoch(epoch, 9) == list(g[f"epochsteps_s{scale}_e{epoch}"])
+    a = base_args(data_size=32, ddpm_schedule="log", ddpm_num_steps=50, select_degrade_pixel="indexing")
+    s = mdm.Scheduler(a, device="cpu")
+    n = s.update_ddpm_num_steps(50)
+    t = torch.from_numpy(g["gather_log_idx_t"])
+    assert np.array_equal(s.get_black_area_num_pixels_time(t).numpy(), g["gather_log_idx"])
+    a.select_degrade_pixel = "thresholding"
+    assert np.array_equal(s.get_black_area_num_pixels_time(t.float()).numpy(), g["gather_log_thr"])
+    assert np.array_equal(s.get_weight_timesteps(torch.tensor([0, 1, 7, n - 1]), 10.0).numpy(), g["lossw"])
+    with pytest.raises(TypeError):
+        mdm.Scheduler(base_args(ddpm_schedule="sigmoid"), device="cpu").update_ddpm_num_steps(10)
+    with pytest.raises(ValueError):
+        mdm.Scheduler(base_args(ddpm_schedule="cosine"), device="cpu").update_ddpm_num_steps(10)
+
+
+def test_state_dict_grammar_and_layout_roundtrip():
+    from mdm.unet import ParamStore, UNet, unet6_config
+    from oracle.unet_ref import param_shapes, random_params, unet6_config as ref_cfg
+    for cfg, hw in ((TINY, 16), (unet6_config(32), 32)):
+        table = UNet.param_table(cfg, hw, hw)
+        ref = param_shapes(cfg)
+        assert set(table) == set(ref) and all(tuple(table[k]) == tuple(ref[k]) for k in ref)
+    assert unet6_config(64) == ref_cfg(64) and unet6_config(256) == ref_cfg(256)
+    assert sum(int(np.prod(v)) for v in UNet.param_table(unet6_config(32)).values()) == 35746307
+    net = UNet(TINY, 1, 16, 16, _dry=True)
+    st = net.store
+    p = random_params(TINY, 3)
+    for k in p:                                  # OIHW <-> [tap][O_p][I_p] and the channel padding
+        back = st.to_reference(k, st.to_internal(k, p[k]))
+        assert torch.equal(back, p[k]), k
+    w = st.to_internal("in_conv.weight", p["in_conv.weight"])
+    assert w.shape == (9, 32, 8) and float(w[:, :, 3:].abs().sum()) == 0
+    assert torch.equal(w[4, :, :3], p["in_conv.weight"][:, :, 1, 1])
+    # all time-embedding projections sit back to back (one contraction for the 22 of them)
+    offs = [st.entries[k + ".weight"].off for k in net.fc_slots]
+    sizes = [st.entries[k + ".weight"].n for k in net.fc_slots]
+    assert all(offs[i] + sizes[i] == offs[i + 1] for i in range(len(offs) - 1))
+
+
+def test_bucket_planning():
+    from mdm.dist import GradComm
+    marks = [(10, 900), (20, 600), (30, 590), (45, 100), (50, 0)]
+    cuts, buckets = GradComm.plan_buckets(marks, 1000, 300)
+    assert buckets[0][1] == 1000 and buckets[-1][0] == 0
+    assert all(buckets[i][0] == buckets[i + 1][1] for i in range(len(buckets) - 1))        # tile [0, total)
+    assert cuts == sorted(cuts) and len(cuts) == len(buckets) and cuts[-1] == 50
+    assert all(hi - lo >= 300 for lo, hi in buckets[:-1])
+    cuts1, b1 = GradComm.plan_buckets(marks, 1000, 10 ** 9)                                   # one bucket
+    assert b1 == [(0, 1000)] and cuts1 == [50]
+    net_marks = [(5, 7), (9, 0)]
+    assert GradComm.plan_buckets(net_marks, 8, 1) == ([5, 9], [(7, 8), (0, 7)])
+
+
+def test_ema_and_lr_schedules_per_call_site_arguments():
+    from mdm.optim import EMA, get_lr_scheduler
+    from oracle.trainer_ref import ema_decay
+
+    class _M:        # EMA only touches .store.P here
+        class store:
+            P = torch.zeros(4)
+    e = EMA(_M, decay=0.9999, inv_gamma=1.0, power=0.75)
+    assert e.get_decay(1) == 0.0
+    for k in (2, 10, 1000, 10 ** 7):
+        assert abs(e.get_decay(k) - ema_decay(k)) < 1e-12
+    assert e.get_decay(10 ** 9) == 0.9999
+
+    class _O:
+        param_groups = [dict(lr=1.0, initial_lr=1.0)]
+    for name in ("constant", "linear", "cosine", "hard_cosine"):
+        o = _O()
+        o.param_groups = [dict(lr=1.0, initial_lr=1.0)]
+        s = get_lr_scheduler(name, o, 10, 100)
+        lrs = []
+        for _ in range(100):
+            lrs.append(s.get_last_lr()[0])
+            s.step()
+        assert lrs[0] == 0.0 and abs(lrs[5] - 0.5) < 1e-9 and abs(lrs[10] - 1.0) < 1e-9
+        assert all(0.0 <= v <= 1.0 for v in lrs)
+        if name in ("linear", "cosine"):
+            assert lrs[-1] < 0.1
+
+
+# ------------------------------------------------------------------------------- data parallel over gloo
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "masked-diffusion-model_amd")); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+from mdm.dist import GradComm, init_from_env
+from golden.make_golden import TINY
+from oracle.unet_ref import UNetRef, random_params
+init_from_env("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+# (a) bucketed exchange of a flat buffer == one big all-reduce
+comm = GradComm(bucket_bytes=4 * 300)
+marks = [(3, 700), (5, 400), (9, 0)]
+cuts, comm.buckets = GradComm.plan_buckets(marks, 1000, comm.bucket_bytes // 4)
+flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+for i in range(len(comm.buckets)):
+    comm.reduce_bucket(i, flat)
+comm.wait_all()
+want = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world))
+assert torch.equal(flat, want), "bucketed all-reduce"
+# (b) DP gradient equivalence on the oracle model: mean over ranks of shard-mean grads == full-batch grad
+g = torch.Generator().manual_seed(5)
+x = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+t = torch.tensor([3.0, 9.0, 1.0, 7.0])
+tgt = torch.rand(4, 3, 16, 16, generator=g)
+def flat_grad(xs, ts, ys):
+    m = UNetRef(TINY, random_params(TINY))
+    loss = ((m(xs, ts).sample - ys) ** 2).mean()
+    loss.backward()
+    return torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+full = flat_grad(x, t, tgt)
+sl = slice(rank * 2, rank * 2 + 2)
+mine = flat_grad(x[sl], t[sl], tgt[sl])
+comm2 = GradComm(bucket_bytes=1 << 16)
+n = mine.numel()
+comm2.buckets = [(n // 2, n), (0, n // 2)]
+for i in range(2):
+    comm2.reduce_bucket(i, mine)
+comm2.wait_all()
+mine *= 1.0 / world                      # the optimizer kernel's gmul
+err = float((mine - full).norm() / full.norm())
+assert err < 1e-5, err
+dist.barrier()
+if rank == 0:
+    print("DP_OK", err)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_exchange_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "DP_OK" in outs[0]
