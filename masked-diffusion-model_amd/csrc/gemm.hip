@@ -12,6 +12,8 @@
 //
 // Replaces F.conv2d fwd/dgrad/wgrad, F.linear and the attention einsums
 // (reference unet6.py:170-171, 232-235, 316-324).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mdm {
@@ -33,11 +35,47 @@ struct RowPix { int img, oy, ox; };
 __device__ __forceinline__ RowPix decode_row(const mdm_gemm_desc& d, int row) {
     RowPix r;
     int per = d.OH * d.OW;
+    if (((per & (per - 1)) | (d.OW & (d.OW - 1))) == 0) {      // power-of-two extents (every unet6 level): shifts, no division
+        int sp = 31 - __clz(per), sw = 31 - __clz(d.OW);
+        r.img = row >> sp;
+        int rem = row & (per - 1);
+        r.oy = rem >> sw;
+        r.ox = rem & (d.OW - 1);
+        return r;
+    }
     r.img = row / per;
     int rem = row - r.img * per;
     r.oy = rem / d.OW;
     r.ox = rem - r.oy * d.OW;
     return r;
+}
+
+// source-pixel index that (row pixel, tap ty/tx) reads, or -1 for zero padding
+__device__ __forceinline__ int gather_pix(const mdm_gemm_desc& d, const RowPix& r, int ty, int tx) {
+    int iy, ix;
+    if (!d.transposed) {
+        iy = r.oy * d.stride + ty - d.pad_t;
+        ix = r.ox * d.stride + tx - d.pad_l;
+        if ((unsigned)iy >= (unsigned)d.IH || (unsigned)ix >= (unsigned)d.IW) return -1;
+    } else {
+        iy = r.oy + d.pad_t - ty;
+        ix = r.ox + d.pad_l - tx;
+        if (iy < 0 || ix < 0) return -1;
+        if (d.stride == 2) {
+            if ((iy | ix) & 1) return -1;
+            iy >>= 1; ix >>= 1;
+        }
+        if (iy >= d.IH || ix >= d.IW) return -1;
+    }
+    int sh = d.IH >> d.ups, sw = d.IW >> d.ups;
+    iy >>= d.ups; ix >>= d.ups;
+    return (r.img * sh + iy) * sw + ix;
+}
+template <typename T>
+__device__ __forceinline__ const T* pix_chan_ptr(const mdm_gemm_desc& d, int spix, int c) {
+    if (spix < 0) return nullptr;
+    if (c < d.C0) return reinterpret_cast<const T*>(d.src0) + (int64_t)spix * d.ld0 + c;
+    return reinterpret_cast<const T*>(d.src1) + (int64_t)spix * d.ld1 + (c - d.C0);
 }
 
 // pointer to channel c of the source pixel that (row pixel, tap) reads; nullptr = zero padding
@@ -280,9 +318,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
     constexpr int B_ELEMS = B_ROWS ? BN * LDB : BK * LDB;
     constexpr int NVA = BM * BK / 8 / 256, NVB = BN * BK / 8 / 256;   // 16-byte vectors per thread
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[A_ELEMS + B_ELEMS];
-    bf16_t* As = smem;
-    bf16_t* Bs = smem + A_ELEMS;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];      // double-buffered LDS image
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -306,6 +343,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
             arow[i] = decode_row(d, gm < d.M ? gm : 0);
         }
     }
+    // layout 2 + conv: the filter tap is fixed per workgroup (grid z) -> decode it once
+    const int wg_ty = (LAYOUT == 2 && d.conv) ? z.tap / d.KW : 0;
+    const int wg_tx = (LAYOUT == 2 && d.conv) ? z.tap - wg_ty * d.KW : 0;
+    // Tap-major fast path (layouts 0/1, gathered A): when every BK-slab of the reduction lies inside
+    // one filter tap, the source pixel of each of this thread's rows is computed once per tap and the
+    // hot loop has no integer division at all.
+    const bool tapmajor = A_ROWS && d.conv && (d.Ck % BK == 0);
+    int apix[NVA];
+    int cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        int ty = tap / d.KW, tx = tap - ty * d.KW;         // wave-uniform, once per tap
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) apix[i] = (m0 + rr + 32 * i < d.M) ? gather_pix(d, arow[i], ty, tx) : -1;
+        cur_tap = tap;
+    };
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -314,7 +366,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[NVA], rb[NVB];
+    int nxt_tap = 0, nxt_c = 0;       // (tap, channel offset) of the slab load_tiles() fetches next
     auto load_tiles = [&](int k0) {
+        if (tapmajor) {
+            if (nxt_tap != cur_tap && nxt_tap < d.KH * d.KW) set_tap(nxt_tap);
+            const bool live = nxt_tap < d.KH * d.KW;
+            const int cc = nxt_c + rk;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) ra[i] = ldg16(live ? pix_chan_ptr<bf16_t>(d, apix[i], cc) : nullptr);
+            const bf16_t* Bt = reinterpret_cast<const bf16_t*>(d.B) + (int64_t)nxt_tap * d.wtap;
+            if (B_ROWS) {
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) {
+                    int gn = n0 + rr + 32 * i;
+                    rb[i] = ldg16((live && gn < d.N) ? Bt + (int64_t)gn * d.ldb + cc : nullptr);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) {
+                    int gn = n0 + bcc;
+                    rb[i] = ldg16((live && gn < d.N) ? Bt + (int64_t)(nxt_c + bck + BKP * i) * d.ldb + gn : nullptr);
+                }
+            }
+            nxt_c += BK;
+            if (nxt_c >= d.Ck) { nxt_c = 0; ++nxt_tap; }
+            return;
+        }
         if (A_ROWS) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i)
@@ -328,13 +405,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i)
                 rb[i] = ldg16(b_row_ptr<bf16_t>(d, z, n0 + rr + 32 * i, k0 + rk));
+        } else if (LAYOUT == 2 && d.conv) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                int k = k0 + bck + BKP * i, gn = n0 + bcc;
+                const bf16_t* p = nullptr;
+                if (k < z.kend && gn < d.N) p = pix_chan_ptr<bf16_t>(d, gather_pix(d, decode_row(d, k), wg_ty, wg_tx), gn);
+                rb[i] = ldg16(p);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NVB; ++i)
                 rb[i] = ldg16(b_col_ptr<bf16_t>(d, z, k0 + bck + BKP * i, n0 + bcc));
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
+        bf16_t* As = smem + buf * STAGE;
+        bf16_t* Bs = As + A_ELEMS;
         if (A_ROWS) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) *reinterpret_cast<uint4*>(&As[(rr + 32 * i) * LDA + rk]) = ra[i];
@@ -351,12 +438,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
         }
     };
 
-    load_tiles(z.kbeg);
-    for (int k0 = z.kbeg; k0 < z.kend; k0 += BK) {
-        __syncthreads();                // previous tile fully consumed
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < z.kend) load_tiles(k0 + BK);   // prefetch next tile into registers
+    // Software pipeline over k-slabs: registers hold slab it+1 while slab it is read from LDS stage
+    // it&1; one barrier per slab.  (store waits for loads issued a whole slab ago.)
+    const int nk = tapmajor ? d.KH * d.KW * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tiles(z.kbeg);
+        store_tiles(0);
+        if (nk > 1) load_tiles(z.kbeg + BK);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) store_tiles(cur ^ 1);
+        if (it + 2 < nk) load_tiles(z.kbeg + (it + 2) * BK);
+        const bf16_t* As = smem + cur * STAGE;
+        const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[MI], bfr[NI];
@@ -376,7 +472,273 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
                     // i.e. four consecutive output channels per lane -> 8/16-byte NHWC stores
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = m0 + wr * WM + i * 16 + (lane & 15);
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// bf16 MFMA path, pipelined: NSTAGE-deep LDS ring filled by LDS-DMA (global_load_lds_dwordx4).
+//
+// The register-staged kernel above keeps one k-slab in flight per workgroup and is bound by
+// the memory round trip per slab.  Here every wave issues its share of slab it+NSTAGE-1 straight
+// into LDS while slab `it` feeds the MFMAs, waits with a COUNTED vmcnt and meets the other waves
+// at ONE raw s_barrier per slab (hipcc would drain vmcnt(0) at a __syncthreads()).
+//   * LDS-DMA writes 64 lanes x 16 B contiguously, so images are unpadded and bank conflicts
+//     are handled by an XOR swizzle of the 16-byte chunk index applied to the per-lane SOURCE
+//     address and again on the fragment read (same involution on both sides);
+//   * padding taps, row/col tails and k tails read a zero page instead of being predicated.
+// Eligible: every 64-wide k-slab lies in one filter tap (Ck % 64 == 0), or no gather and
+// K % 64 == 0, or layout 2 (k = rows).  Everything else runs on the kernel above.
+// ----------------------------------------------------------------------------
+__device__ uint4 g_zero_page[64];          // 1 KiB of zeros, the source of every padded 16-byte chunk
+
+__device__ __forceinline__ int swz_rows(int row) { return row & 7; }                       // [rows][64] image, 8 chunks/row
+template <int CPR> __device__ __forceinline__ int swz_cols(int row) {                      // [64][cols] image
+    return CPR == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row ^ (row >> 3)) & 7);
+}
+
+__device__ __forceinline__ void lds_dma16(const void* src, char* lds_piece_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_piece_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 ring_frag_rows(const char* tile, int row0, int ks, int lane) {
+    int row = row0 + (lane & 15);
+    int ch = (ks * 4 + (lane >> 4)) ^ swz_rows(row);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (ch << 4));
+}
+template <int CPR>
+__device__ __forceinline__ bf16x8 ring_frag_cols(const char* tile, int col0, int ks, int lane) {
+    const int i = lane & 15;
+    const int kb = ks * 32 + 8 * (lane >> 4) + (i >> 2);
+    const int col = col0 + 4 * (i & 3);
+    const int ch = col >> 3, half = (col >> 2) & 1;
+    const char* p0 = tile + kb * (CPR * 16) + ((ch ^ swz_cols<CPR>(kb)) << 4) + half * 8;
+    const char* p1 = tile + (kb + 4) * (CPR * 16) + ((ch ^ swz_cols<CPR>(kb + 4)) << 4) + half * 8;
+    bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(p0));
+    bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(p1));
+    bf16x4 l4 = *reinterpret_cast<bf16x4*>(&lo), h4 = *reinterpret_cast<bf16x4*>(&hi);
+    bf16x8 f;
+    f[0] = l4[0]; f[1] = l4[1]; f[2] = l4[2]; f[3] = l4[3];
+    f[4] = h4[0]; f[5] = h4[1]; f[6] = h4[2]; f[7] = h4[3];
+    return f;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// select without a branch: p if ok else the zero page
+__device__ __forceinline__ const void* or_zero(bool ok, const void* p, const void* zero) { return ok ? p : zero; }
+
+template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(mdm_gemm_desc d) {
+    constexpr int BK = 64;
+    constexpr bool A_ROWS = (LAYOUT != 2), B_ROWS = (LAYOUT == 0);
+    constexpr bool TAPMAJOR = A_ROWS && CONV;          // reduction index = (tap, channel), slab inside one tap
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int GA = A_BYTES / 1024 / 4, GB = B_BYTES / 1024 / 4, G = GA + GB;     // LDS-DMA pieces per wave per slab
+    constexpr int ACPR = BM / 8, BCPR = BN / 8;                                     // chunks per row of a [64][cols] image
+    constexpr int A_RPP = 64 / ACPR, B_RPP = 64 / BCPR;                             // k-rows per 1-KiB piece of such an image
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const ZInfo z = decode_z(d, BK);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const bf16_t* Abase = reinterpret_cast<const bf16_t*>(d.A) + z.batch * d.sA;
+    const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(d.B) + z.batch * d.sB;
+    const bf16_t* S0 = reinterpret_cast<const bf16_t*>(d.src0);
+    const bf16_t* S1 = reinterpret_cast<const bf16_t*>(d.src1);
+
+    // per-lane geometry of the pieces this wave fills (fixed for the whole k loop)
+    const int r_sub = lane >> 3;                          // rows image: piece p covers rows 8p..8p+7
+    const int r_lch = (lane & 7) ^ r_sub;                 // logical chunk (swizzle depends on row&7 = lane>>3 only)
+    const int ac_row = lane / ACPR, ac_pch = lane % ACPR; // cols image: lane -> (k-row in piece, physical chunk)
+    const int bc_row = lane / BCPR, bc_pch = lane % BCPR;
+
+    // ---- hoisted address generation --------------------------------------------------------
+    // Every LDS-DMA piece of this lane has a base pointer that is fixed for a whole segment of the
+    // k loop (the whole loop for weights / plain operands, one (tap, source) pair for gathered
+    // pixels) plus a WAVE-UNIFORM element offset that advances per slab.  Padding / tails point the
+    // base at the zero page and freeze the offset (step 0), so the hot loop is a 64-bit add per piece.
+    const char* a_base[GA];
+    int a_step[GA];                     // 1: follows the slab offset, 0: zero page
+    const char* b_base[GB];
+    int b_step[GB];
+    int a_img[GA], a_oy[GA], a_ox[GA];
+    bool a_ok[GA];
+    const int wg_ty = (LAYOUT == 2 && CONV) ? z.tap / d.KW : 0;
+    const int wg_tx = (LAYOUT == 2 && CONV) ? z.tap - wg_ty * d.KW : 0;
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        a_img[j] = a_oy[j] = a_ox[j] = 0;
+        a_base[j] = zero; a_step[j] = 0; a_ok[j] = false;
+        const int piece = wave * GA + j;
+        if (A_ROWS) {
+            const int gm = m0 + 8 * piece + r_sub;
+            a_ok[j] = gm < d.M;
+            if (TAPMAJOR) {
+                RowPix rp = decode_row(d, a_ok[j] ? gm : 0);
+                a_img[j] = rp.img; a_oy[j] = rp.oy; a_ox[j] = rp.ox;
+            } else if (a_ok[j]) {
+                a_base[j] = reinterpret_cast<const char*>(Abase + (int64_t)gm * d.lda + 8 * r_lch);
+                a_step[j] = 1;
+            }
+        } else {
+            const int kl = piece * A_RPP + ac_row;
+            const int gm = m0 + 8 * (ac_pch ^ swz_cols<ACPR>(kl));
+            a_ok[j] = gm < d.M;
+            a_base[j] = reinterpret_cast<const char*>(Abase + (int64_t)kl * d.lda + gm);   // + k*lda per slab
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        b_base[j] = zero; b_step[j] = 0;
+        const int piece = wave * GB + j;
+        if (B_ROWS) {
+            const int gn = n0 + 8 * piece + r_sub;
+            if (gn < d.N) { b_base[j] = reinterpret_cast<const char*>(Bbase + (int64_t)gn * d.ldb + 8 * r_lch); b_step[j] = 1; }
+        } else {
+            const int kl = piece * B_RPP + bc_row;
+            const int gn = n0 + 8 * (bc_pch ^ swz_cols<BCPR>(kl));
+            if (gn < d.N) {
+                b_step[j] = 1;
+                if (LAYOUT == 1) b_base[j] = reinterpret_cast<const char*>(Bbase + (int64_t)kl * d.ldb + gn);
+                else if (!CONV) b_base[j] = reinterpret_cast<const char*>(Bbase + (int64_t)kl * d.ldb + gn);
+            }
+        }
+    }
+    // slab cursor.  TAPMAJOR: segment = (tap, source); c runs over that source's channels.
+    int seg_tap = 0, seg_src = 0, seg_c = 0, tap_ty = 0, tap_tx = 0;
+    bool seg_dirty = true;
+    int nxt_k = z.kbeg;
+    const int nsrc = (TAPMAJOR && d.C1 > 0) ? 2 : 1;
+
+#define MDM_RING_ISSUE(SLAB)                                                                                          \
+    do {                                                                                                              \
+        char* stage = ring + ((SLAB) % NSTAGE) * STAGE_BYTES;                                                         \
+        const bool live = (SLAB) < nk;     /* over-issued tail slabs read the zero page only */                      \
+        /* ------------------------------------------------ A */                                                      \
+        if (TAPMAJOR) {                                                                                               \
+            if (seg_dirty) {              /* new (tap, source): re-aim the gathered pixel pointers */                \
+                const bf16_t* S = seg_src ? S1 : S0;                                                                  \
+                const int ld = seg_src ? d.ld1 : d.ld0;                                                               \
+                _Pragma("unroll") for (int j = 0; j < GA; ++j) {                                                      \
+                    RowPix rp = {a_img[j], a_oy[j], a_ox[j]};                                                         \
+                    const int spix = (a_ok[j] && live) ? gather_pix(d, rp, tap_ty, tap_tx) : -1;                      \
+                    a_step[j] = spix >= 0;                                                                            \
+                    a_base[j] = spix >= 0 ? reinterpret_cast<const char*>(S + (int64_t)spix * ld + 8 * r_lch) : zero; \
+                }                                                                                                     \
+                seg_dirty = false;                                                                                    \
+            }                                                                                                         \
+            const int64_t aoff = (int64_t)seg_c * 2;                                                                  \
+            _Pragma("unroll") for (int j = 0; j < GA; ++j)                                                            \
+                lds_dma16(a_base[j] + (a_step[j] ? aoff : 0), stage + (wave * GA + j) * 1024);                        \
+        } else if (A_ROWS) {                                                                                          \
+            const int64_t aoff = live ? (int64_t)nxt_k * 2 : 0;                                                       \
+            _Pragma("unroll") for (int j = 0; j < GA; ++j)                                                            \
+                lds_dma16((live && a_step[j]) ? a_base[j] + aoff : zero, stage + (wave * GA + j) * 1024);             \
+        } else {                                                                                                      \
+            const int64_t aoff = (int64_t)nxt_k * d.lda * 2;                                                          \
+            _Pragma("unroll") for (int j = 0; j < GA; ++j) {                                                          \
+                const int k = nxt_k + (wave * GA + j) * A_RPP + ac_row;                                               \
+                lds_dma16((a_ok[j] && k < z.kend) ? a_base[j] + aoff : zero, stage + (wave * GA + j) * 1024);          \
+            }                                                                                                         \
+        }                                                                                                             \
+        /* ------------------------------------------------ B */                                                      \
+        char* bst = stage + A_BYTES;                                                                                  \
+        if (B_ROWS || LAYOUT == 1) {                                                                                  \
+            int64_t boff;                                                                                             \
+            if (TAPMAJOR) {                                                                                           \
+                const int cg = seg_c + (seg_src ? d.C0 : 0);         /* channel index inside the tap */              \
+                boff = B_ROWS ? ((int64_t)seg_tap * d.wtap + cg) * 2 : ((int64_t)seg_tap * d.wtap + (int64_t)cg * d.ldb) * 2; \
+            } else {                                                                                                  \
+                boff = B_ROWS ? (int64_t)nxt_k * 2 : (int64_t)nxt_k * d.ldb * 2;                                      \
+            }                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < GB; ++j)                                                            \
+                lds_dma16((live && b_step[j]) ? b_base[j] + boff : zero, bst + (wave * GB + j) * 1024);               \
+        } else if (CONV) {                /* layout 2: rows of B are gathered pixels of this slab */                 \
+            _Pragma("unroll") for (int j = 0; j < GB; ++j) {                                                          \
+                const int kl = (wave * GB + j) * B_RPP + bc_row;                                                      \
+                const int k = nxt_k + kl;                                                                             \
+                const int gn = n0 + 8 * (bc_pch ^ swz_cols<BCPR>(kl));                                                \
+                const int spix = gather_pix(d, decode_row(d, k < z.kend ? k : 0), wg_ty, wg_tx);                      \
+                const int px = spix < 0 ? 0 : spix;                                                                   \
+                const bf16_t* q = gn < d.C0 ? S0 + (int64_t)px * d.ld0 + gn : S1 + (int64_t)px * d.ld1 + (gn - d.C0); \
+                lds_dma16(or_zero(b_step[j] && spix >= 0 && k < z.kend, q, zero), bst + (wave * GB + j) * 1024);      \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            const int64_t boff = (int64_t)nxt_k * d.ldb * 2;                                                          \
+            _Pragma("unroll") for (int j = 0; j < GB; ++j) {                                                          \
+                const int k = nxt_k + (wave * GB + j) * B_RPP + bc_row;                                               \
+                lds_dma16((b_step[j] && k < z.kend) ? b_base[j] + boff : zero, bst + (wave * GB + j) * 1024);          \
+            }                                                                                                         \
+        }                                                                                                             \
+        /* ------------------------------------------------ advance */                                                \
+        if (TAPMAJOR) {                                                                                               \
+            seg_c += BK;                                                                                              \
+            if (seg_c >= (seg_src ? d.C1 : d.C0)) {                                                                   \
+                seg_c = 0; seg_dirty = true;                                                                          \
+                if (++seg_src == nsrc) {                                                                              \
+                    seg_src = 0; ++seg_tap;                                                                           \
+                    if (++tap_tx == d.KW) { tap_tx = 0; ++tap_ty; }                                                   \
+                }                                                                                                     \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            nxt_k += BK;                                                                                              \
+        }                                                                                                             \
+    } while (0)
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = TAPMAJOR ? d.KH * d.KW * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
+    // prologue: NSTAGE-1 slabs in flight.  Slabs past the end are issued too (all-zero or harmless
+    // re-reads) so that the vmcnt bookkeeping below is the same for every trip count.
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) MDM_RING_ISSUE(s);
+
+    for (int it = 0; it < nk; ++it) {
+        wait_vmcnt<(NSTAGE - 2) * G>();        // slab `it` of THIS wave has landed ...
+        __builtin_amdgcn_s_barrier();          // ... and of every wave; slab it-1 is fully consumed
+        MDM_RING_ISSUE(it + NSTAGE - 1);       // refill the stage that slab it-1 occupied
+        const char* As = ring + (it % NSTAGE) * STAGE_BYTES;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = A_ROWS ? ring_frag_rows(As, wr * WM + i * 16, ks, lane)
+                               : ring_frag_cols<ACPR>(As, wr * WM + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[j] = B_ROWS ? ring_frag_rows(Bs, wc * WN + j * 16, ks, lane)
+                                : ring_frag_cols<BCPR>(Bs, wc * WN + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    wait_vmcnt<0>();                           // the over-issued tail slabs must land before the workgroup retires
+#undef MDM_RING_ISSUE
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         int m = m0 + wr * WM + i * 16 + (lane & 15);
@@ -429,6 +791,35 @@ static int validate(const mdm_gemm_desc& d) {
     return 0;
 }
 
+template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV>
+static int launch_ring_one(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV>), grid, dim3(256), bytes, s, d);
+    return 0;
+}
+template <int BM, int BN, int NSTAGE>
+static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    const bool c = d.conv != 0;
+    switch (d.layout) {
+        case 0: return c ? launch_ring_one<BM, BN, 0, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 0, NSTAGE, false>(d, grid, s);
+        case 1: return c ? launch_ring_one<BM, BN, 1, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 1, NSTAGE, false>(d, grid, s);
+        default: return c ? launch_ring_one<BM, BN, 2, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 2, NSTAGE, false>(d, grid, s);
+    }
+}
+
+static bool ring_eligible(const mdm_gemm_desc& d) {
+    if (d.dtype != MDM_BF16) return false;
+    if (d.layout == 2) return true;
+    if (d.conv) return d.Ck % 64 == 0 && d.C0 % 64 == 0 && d.C1 % 64 == 0;
+    return d.K % 64 == 0;
+}
+
 template <int BM, int BN>
 static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     switch (d.layout) {
@@ -438,6 +829,10 @@ static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     }
 }
 
+static int g_use_ring = []() { const char* e = getenv("MDM_NO_RING"); return (e && e[0] == '1') ? 0 : 1; }();
+static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
+
 int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     MDM_REQUIRE(dh != nullptr, "gemm: null descriptor");
     mdm_gemm_desc d = *dh;
@@ -445,7 +840,7 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     if (int rc = validate(d)) return rc;
     int zouter = d.batch;
     if (d.layout == 2 && d.conv) zouter = d.KH * d.KW;
-    const bool big = d.dtype == MDM_BF16 &&
+    const bool big = d.dtype == MDM_BF16 && !g_force_small &&
                      (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= 200 && d.N >= 128 && d.M >= 128;
     const int BM = d.dtype == MDM_F32 ? 64 : (big ? 128 : 64), BN = BM;
     const int BK = d.dtype == MDM_F32 ? 16 : 64;
@@ -469,6 +864,10 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
+    } else if (g_use_ring && ring_eligible(d)) {
+        int rc = big ? launch_ring<128, 128, 3>(d, grid, s)
+                     : (g_stages64 == 3 ? launch_ring<64, 64, 3>(d, grid, s) : launch_ring<64, 64, 4>(d, grid, s));
+        if (rc) return rc;
     } else if (big) {
         launch_bf16<128, 128>(d, grid, s);
     } else {
