@@ -110,15 +110,13 @@ __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
     ZInfo z;
     z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K;
     int zi = blockIdx.z;
-    if (d.layout == 2) {
-        int sk = d.splitk < 1 ? 1 : d.splitk;
-        int outer = zi / sk, ks = zi - outer * sk;
-        if (d.conv) z.tap = outer; else z.batch = outer;
+    int sk = d.splitk < 1 ? 1 : d.splitk;
+    int outer = zi / sk, ks = zi - outer * sk;
+    if (d.layout == 2 && d.conv) z.tap = outer; else z.batch = outer;
+    if (sk > 1) {
         int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
         z.kbeg = ks * chunk;
         z.kend = min(d.K, z.kbeg + chunk);
-    } else {
-        z.batch = zi;
     }
     return z;
 }
@@ -142,7 +140,7 @@ __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z
     if (n < d.N0) { base = d.D0; ld = d.ldd0; col = n; acc = d.acc0; }
     else          { base = d.D1; ld = d.ldd1; col = n - d.N0; acc = d.acc1; }
     int64_t off = z.batch * d.sD + z.tap * d.dtap + (int64_t)m * ld + col;
-    if (d.layout == 2 && d.splitk > 1) {
+    if (d.splitk > 1) {
         float* p = reinterpret_cast<float*>(base) + off;
         atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
     } else if (d.out_f32) {
@@ -159,7 +157,7 @@ __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z
 // address of VEC consecutive k-elements of A-row `gm` starting at reduction index k (layouts 0/1)
 template <typename T>
 __device__ __forceinline__ const T* a_row_ptr(const mdm_gemm_desc& d, const ZInfo& z, int gm, const RowPix& rp, int k) {
-    if (gm >= d.M || k >= d.K) return nullptr;
+    if (gm >= d.M || k >= z.kend) return nullptr;
     if (d.conv) {
         int tap = k / d.Ck, c = k - tap * d.Ck;
         return gather_ptr<T>(d, rp, tap, c);
@@ -169,7 +167,7 @@ __device__ __forceinline__ const T* a_row_ptr(const mdm_gemm_desc& d, const ZInf
 // layout 0: VEC consecutive k of B-row gn
 template <typename T>
 __device__ __forceinline__ const T* b_row_ptr(const mdm_gemm_desc& d, const ZInfo& z, int gn, int k) {
-    if (gn >= d.N || k >= d.K) return nullptr;
+    if (gn >= d.N || k >= z.kend) return nullptr;
     const T* B = reinterpret_cast<const T*>(d.B) + z.batch * d.sB;
     if (d.conv) {
         int tap = k / d.Ck, c = k - tap * d.Ck;
@@ -787,7 +785,10 @@ static int validate(const mdm_gemm_desc& d) {
     }
     if (d.rowvec) MDM_REQUIRE(d.rows_per_img > 0 && d.rv_ld % 4 == 0, "gemm: bad rowvec params");
     if (d.resid) MDM_REQUIRE(d.ldr % 4 == 0, "gemm: bad resid pitch");
-    if (d.layout == 2 && d.splitk > 1) MDM_REQUIRE(d.out_f32 || d.dtype == MDM_F32, "gemm: split-K needs an fp32 destination");
+    if (d.splitk > 1) MDM_REQUIRE(d.out_f32 || d.dtype == MDM_F32, "gemm: split-K needs an fp32 destination");
+    if (d.splitk > 1 && d.layout != 2)
+        MDM_REQUIRE(!d.conv && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f,
+                    "gemm: split-K in layouts 0/1 is for plain contractions without an epilogue");
     return 0;
 }
 
@@ -816,6 +817,7 @@ static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
+    if (d.splitk > 1) return false;
     if (d.conv) return d.Ck % 64 == 0 && d.C0 % 64 == 0 && d.C1 % 64 == 0;
     return d.K % 64 == 0;
 }
@@ -852,11 +854,11 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             d.splitk = (int)(want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want));
             if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
         }
-    } else {
+    } else if (d.splitk < 1 || d.conv) {
         d.splitk = 1;
     }
     MDM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
-    dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * (d.layout == 2 ? d.splitk : 1)));
+    dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * d.splitk));
     MDM_REQUIRE(grid.z <= 65535, "gemm: grid.z=%u too large", grid.z);
     if (d.dtype == MDM_F32) {
         switch (d.layout) {

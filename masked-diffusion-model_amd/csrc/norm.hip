@@ -31,7 +31,7 @@ __device__ __forceinline__ const T* src_ptr(const T* s0, const T* s1, int C0, in
     return c < C0 ? s0 + pix * C0 + c : s1 + pix * C1 + (c - C0);
 }
 
-constexpr int GN_SLAB = 8;    // passes per workgroup: a workgroup covers GN_SLAB * pix_per_pass pixels of one image
+constexpr int GN_MAX_SLABS = 32;   // workgroups per image at most (bounds the partial-sum scratch)
 
 // ---- forward pass 1: per (image, group) SHIFTED sums  sum(x-K), sum((x-K)^2) -> ws[N][G][2]
 // K = the group's first element of that image.  Shifting removes the cancellation of
@@ -55,14 +55,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* s0, int C0, cons
         float s[8] = {}, q[8] = {}, K[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, (c + e) / g.cpg, g.cpg);
-        const int p_beg = blockIdx.x * GN_SLAB * g.pix_per_pass;
-        const int p_end = min(P, p_beg + GN_SLAB * g.pix_per_pass);
-        for (int p = p_beg + t / g.VPP; p < p_end; p += g.pix_per_pass) {
-            float8 x = load8(src_ptr(s0, s1, C0, C1, (int64_t)img * P + p, c));
+        const int span = (P + gridDim.x - 1) / gridDim.x;     // pixels per workgroup
+        const int p_beg = blockIdx.x * span;
+        const int p_end = min(P, p_beg + span);
+        auto add = [&](const float8& x) {
             float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; s[e] += dlt; q[e] = fmaf(dlt, dlt, q[e]); }
+        };
+        const int st = g.pix_per_pass;
+        int p = p_beg + t / g.VPP;
+        const int64_t base = (int64_t)img * P;
+        for (; p + 3 * st < p_end; p += 4 * st) {          // four independent 16-byte loads in flight per lane
+            float8 x0 = load8(src_ptr(s0, s1, C0, C1, base + p, c));
+            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + st, c));
+            float8 x2 = load8(src_ptr(s0, s1, C0, C1, base + p + 2 * st, c));
+            float8 x3 = load8(src_ptr(s0, s1, C0, C1, base + p + 3 * st, c));
+            add(x0); add(x1); add(x2); add(x3);
         }
+        for (; p < p_end; p += st) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int grp = (c + e) / g.cpg;
@@ -71,41 +82,67 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* s0, int C0, cons
         }
     }
     __syncthreads();
-    if (t < 2 * G) atomicAdd(&ws[(int64_t)img * G * 2 + t], red[t]);
+    if (t < 2 * G) ws[((int64_t)img * gridDim.x + blockIdx.x) * 2 * G + t] = red[t];     // partial of this slab
 }
 
+// per (image, channel): sum the slab partials of the channel's group, finish mean / rstd (group
+// leader also stores them in `stats` for the backward), emit {mean, rstd*gamma} so the streaming
+// pass does two vector loads instead of per-element look-ups.  y = (x-mean)*a + beta keeps x-mean exact.
 template <typename T>
-__global__ void gn_finalize_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, const float* ws, float* stats,
-                                   int n, float inv_cnt, float eps) {
+__global__ void gn_coef_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, const float* ws, int nblk,
+                               const float* gamma, float inv_cnt, float eps, float* stats, float2* coef, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;      // over N*C
+    if (i >= n) return;
+    const int C = C0 + C1, cpg = C / G;
+    int img = i / C, c = i - img * C, grp = c / cpg;
+    float sd = 0.f, sq = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float* p = ws + ((int64_t)img * nblk + b) * 2 * G + 2 * grp;
+        sd += p[0]; sq += p[1];
+    }
+    float K = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, grp, cpg);
+    float md = sd * inv_cnt;
+    float var = fmaxf(sq * inv_cnt - md * md, 0.f);
+    float mean = K + md, rstd = rsqrtf(var + eps);
+    if (c == grp * cpg) { stats[((int64_t)img * G + grp) * 2] = mean; stats[((int64_t)img * G + grp) * 2 + 1] = rstd; }
+    coef[i] = make_float2(mean, rstd * gamma[c]);
+}
+// backward: {mean, rstd, rstd*s1/cnt, rstd*s2/cnt}
+__global__ void gn_bwd_coef_kernel(const float* stats, const float* ws, int nblk, int C, int G, float inv_cnt, float4* coef, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int img = i / G, grp = i - img * G;
-    float K = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, grp, (C0 + C1) / G);
-    float md = ws[2 * i] * inv_cnt;
-    float var = fmaxf(ws[2 * i + 1] * inv_cnt - md * md, 0.f);
-    stats[2 * i] = K + md;
-    stats[2 * i + 1] = rsqrtf(var + eps);
+    int img = i / C, c = i - img * C, grp = c / (C / G);
+    float a1 = 0.f, a2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float* p = ws + ((int64_t)img * nblk + b) * 2 * G + 2 * grp;
+        a1 += p[0]; a2 += p[1];
+    }
+    int64_t si = ((int64_t)img * G + grp) * 2;
+    float mean = stats[si], rstd = stats[si + 1];
+    coef[i] = make_float4(mean, rstd, rstd * a1 * inv_cnt, rstd * a2 * inv_cnt);
 }
 
-// ---- forward pass 2: y = act((x - mean) * rstd * gamma + beta)
+// ---- forward pass 2: y = act((x - mean) * (rstd*gamma) + beta)
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G,
-                                                       const float* gamma, const float* beta, const float* stats,
-                                                       int silu, T* y, int64_t total_vec) {
-    const int C = C0 + C1, VPP = C / 8, cpg = C / G;
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* s0, int C0, const T* s1, int C1, int P,
+                                                       const float2* coef, const float* beta, int silu, T* y, int64_t total_vec) {
+    const int C = C0 + C1, VPP = C / 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t pix = i / VPP;
         int c = (int)(i - pix * VPP) * 8;
         int img = (int)(pix / P);
         float8 x = load8(src_ptr(s0, s1, C0, C1, pix, c));
-        float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
+        const float4* cf = reinterpret_cast<const float4*>(coef + (int64_t)img * C + c);     // 8 x {mean, a}
+        float4 c01 = cf[0], c23 = cf[1], c45 = cf[2], c67 = cf[3];
+        float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
         float o[8];
+        o[0] = fmaf(x.lo.x - c01.x, c01.y, b0.x); o[1] = fmaf(x.lo.y - c01.z, c01.w, b0.y);
+        o[2] = fmaf(x.lo.z - c23.x, c23.y, b0.z); o[3] = fmaf(x.lo.w - c23.z, c23.w, b0.w);
+        o[4] = fmaf(x.hi.x - c45.x, c45.y, b1.x); o[5] = fmaf(x.hi.y - c45.z, c45.w, b1.y);
+        o[6] = fmaf(x.hi.z - c67.x, c67.y, b1.z); o[7] = fmaf(x.hi.w - c67.z, c67.w, b1.w);
+        if (silu) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / cpg;
-            float mean = stats[((int64_t)img * G + grp) * 2], rstd = stats[((int64_t)img * G + grp) * 2 + 1];
-            float zv = (xv[e] - mean) * rstd * gamma[c + e] + beta[c + e];
-            o[e] = silu ? silu_f(zv) : zv;
+            for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
         }
         float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
         store8(y + pix * C + c, r);
@@ -135,12 +172,10 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* s0, int C0, 
             mean[e] = stats[((int64_t)img * G + grp) * 2]; rstd[e] = stats[((int64_t)img * G + grp) * 2 + 1];
         }
         float a1[8] = {}, a2[8] = {}, dg[8] = {}, db[8] = {};
-        const int p_beg = blockIdx.x * GN_SLAB * g.pix_per_pass;
-        const int p_end = min(P, p_beg + GN_SLAB * g.pix_per_pass);
-        for (int p = p_beg + t / g.VPP; p < p_end; p += g.pix_per_pass) {
-            int64_t pix = (int64_t)img * P + p;
-            float8 x = load8(src_ptr(s0, s1, C0, C1, pix, c));
-            float8 d = load8(dy + pix * g.C + c);
+        const int span = (P + gridDim.x - 1) / gridDim.x;
+        const int p_beg = blockIdx.x * span;
+        const int p_end = min(P, p_beg + span);
+        auto add = [&](const float8& x, const float8& d) {
             float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
             float dv[8] = {d.lo.x, d.lo.y, d.lo.z, d.lo.w, d.hi.x, d.hi.y, d.hi.z, d.hi.w};
 #pragma unroll
@@ -152,7 +187,18 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* s0, int C0, 
                 float gg = gz * ga[e];
                 a1[e] += gg; a2[e] = fmaf(gg, xh, a2[e]);
             }
+        };
+        const int st = g.pix_per_pass;
+        int p = p_beg + t / g.VPP;
+        const int64_t base = (int64_t)img * P;
+        for (; p + st < p_end; p += 2 * st) {              // two pixel rows (four 16-byte loads) in flight per lane
+            float8 x0 = load8(src_ptr(s0, s1, C0, C1, base + p, c));
+            float8 d0 = load8(dy + (base + p) * g.C + c);
+            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + st, c));
+            float8 d1 = load8(dy + (base + p + st) * g.C + c);
+            add(x0, d0); add(x1, d1);
         }
+        for (; p < p_end; p += st) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * g.C + c));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int grp = (c + e) / g.cpg;
@@ -163,21 +209,20 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* s0, int C0, 
         }
     }
     __syncthreads();
-    if (t < 2 * G) atomicAdd(&ws[(int64_t)img * G * 2 + t], red[t]);
+    if (t < 2 * G) ws[((int64_t)img * gridDim.x + blockIdx.x) * 2 * G + t] = red[t];
     for (int i = t; i < g.C; i += 256) {                    // one global atomic per channel per workgroup
         atomicAdd(&dgamma[i], chan[i]);
         atomicAdd(&dbeta[i], chan[g.C + i]);
     }
 }
 
-// ---- backward pass 2: dx = rstd * (g*gamma - (s1 + xhat*s2)/cnt)
+// ---- backward pass 2: dx = rstd*gamma*g - (rstd*s1/cnt + xhat*rstd*s2/cnt),  g = dy * act'(xhat*gamma + beta)
 template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* s0, int C0, const T* s1, int C1, int P,
                                                            const float* gamma, const float* beta, int silu,
-                                                           const T* dy, const float* stats, const float* ws,
+                                                           const T* dy, const float4* coef,
                                                            T* d0, int acc0, T* d1, int acc1, int64_t total_vec) {
-    const int C = C0 + C1, VPP = C / 8, cpg = C / G;
-    const float inv_cnt = 1.f / ((float)cpg * (float)P);
+    const int C = C0 + C1, VPP = C / 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t pix = i / VPP;
         int c = (int)(i - pix * VPP) * 8;
@@ -186,16 +231,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* s0, int C0, 
         float8 d = load8(dy + pix * C + c);
         float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
         float dv[8] = {d.lo.x, d.lo.y, d.lo.z, d.lo.w, d.hi.x, d.hi.y, d.hi.z, d.hi.w};
+        const float4* cf = coef + (int64_t)img * C + c;
+        float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
+        float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
+        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / cpg;
-            int64_t si = ((int64_t)img * G + grp) * 2;
-            float mean = stats[si], rstd = stats[si + 1];
-            float xh = (xv[e] - mean) * rstd;
+            float4 k = cf[e];                          // mean, rstd, rstd*s1/cnt, rstd*s2/cnt
+            float xh = (xv[e] - k.x) * k.y;
             float gz = dv[e];
-            if (silu) gz *= silu_grad_f(xh * gamma[c + e] + beta[c + e]);
-            o[e] = rstd * (gz * gamma[c + e] - (ws[si] + xh * ws[si + 1]) * inv_cnt);
+            if (silu) gz *= silu_grad_f(fmaf(xh, gv[e], bv[e]));
+            o[e] = k.y * gv[e] * gz - fmaf(xh, k.w, k.z);
         }
         T* dst; int acc;
         if (c < C0) { dst = d0 + pix * C0 + c; acc = acc0; } else { dst = d1 + pix * C1 + (c - C0); acc = acc1; }
@@ -382,22 +430,27 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
     return 0;
 }
 
+// ws layout: [N][nblk][G][2] slab partials (nblk <= GN_MAX_SLABS), then [N][C] float4 coefficient slots
+static inline int gn_slabs(int P, int ppp) {
+    int nb = cdiv(P, 8 * ppp);                    // ~8 passes per workgroup
+    return nb < 1 ? 1 : (nb > GN_MAX_SLABS ? GN_MAX_SLABS : nb);
+}
 extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                  float eps, const float* gamma, const float* beta, int silu, void* y, float* stats,
                                  float* ws, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    // a kernel, not hipMemsetAsync: the call sits inside captured hipGraphs
-    hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(2 * N * G, 256)), dim3(256), 0, s, ws, 2 * N * G);
     const int C = C0 + C1, ppp = (256 / (C / 8)) < 1 ? 1 : 256 / (C / 8);
-    dim3 g1(cdiv(P, GN_SLAB * ppp), N);
+    const int nblk = gn_slabs(P, ppp);
+    dim3 g1(nblk, N);
     const int64_t tv = (int64_t)N * P * (C / 8);
+    float2* coef = reinterpret_cast<float2*>(ws + (int64_t)N * GN_MAX_SLABS * 2 * G);
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL((gn_stats_kernel<T>), g1, dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1, P, G, ws);
-        hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1,
-                           P, G, ws, stats, N * G, 1.f / ((float)(C / G) * (float)P), eps);
+        hipLaunchKernelGGL((gn_coef_kernel<T>), dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1, P, G,
+                           ws, nblk, gamma, 1.f / ((float)(C / G) * (float)P), eps, stats, coef, N * C);
         hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1,
-                           P, G, gamma, beta, stats, silu, (T*)y, tv);
+                           P, coef, beta, silu, (T*)y, tv);
     });
     return launch_status("groupnorm_fwd");
 }
@@ -408,16 +461,18 @@ extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void
                                  void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    // a kernel, not hipMemsetAsync: the call sits inside captured hipGraphs
-    hipLaunchKernelGGL(zero_f32_kernel, dim3(cdiv(2 * N * G, 256)), dim3(256), 0, s, ws, 2 * N * G);
     const int C = C0 + C1, ppp = (256 / (C / 8)) < 1 ? 1 : 256 / (C / 8);
-    dim3 g1(cdiv(P, GN_SLAB * ppp), N);
+    const int nblk = gn_slabs(P, ppp);
+    dim3 g1(nblk, N);
     const int64_t tv = (int64_t)N * P * (C / 8);
+    float4* coef = reinterpret_cast<float4*>(ws + (int64_t)N * GN_MAX_SLABS * 2 * G);
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), g1, dim3(256), 2 * C * sizeof(float), s, (const T*)src0, C0, (const T*)src1, C1, P, G, gamma,
                            beta, silu, (const T*)dy, stats, ws, dgamma, dbeta);
+        hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, stats, ws, nblk, C, G,
+                           1.f / ((float)(C / G) * (float)P), coef, N * C);
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1,
-                           C1, P, G, gamma, beta, silu, (const T*)dy, stats, ws, (T*)dst0, acc0, (T*)dst1, acc1, tv);
+                           C1, P, gamma, beta, silu, (const T*)dy, coef, (T*)dst0, acc0, (T*)dst1, acc1, tv);
     });
     return launch_status("groupnorm_bwd");
 }

@@ -291,7 +291,8 @@ class _Temb:
         d_st, d_tm, d_a1, d_h1 = f(N, te), f(N, te), f(N, te), f(N, te)
         ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1)
         ops.colsum(F32, n.dT_all, 1, N, ft, dbias=n.fc_gb)
-        ops.matmul(F32, 1, N, te, ft, n.dT_all, ft, n.fc_w, te, d_st, te)
+        ops.fill(d_st, 0.0)                                   # K = sum(Cout) ~ 5k against M = batch: split the reduction
+        ops.matmul(F32, 1, N, te, ft, n.dT_all, ft, n.fc_w, te, d_st, te, splitk=max(1, min(32, ft // 128)))
         ops.silu_bwd(self.tm, d_st, d_tm, 0, N * te)
         ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g("embed.2.weight"), te, acc=1, out_f32=1)
         ops.colsum(F32, d_tm, 1, N, te, dbias=st.g("embed.2.bias"))
@@ -501,7 +502,8 @@ class UNet:
         self.T_all = self.alloc((self.N, ft), torch.float32)
         self.dT_all = self.alloc((self.N, ft), torch.float32)
         self.t_in = self.alloc((self.N,), torch.float32)
-        self.gn_ws = self.alloc((self.N, 32, 2), torch.float32)
+        cmax = max(a.C for a in self.acts)
+        self.gn_ws = self.alloc((self.N * (64 * 32 + 4 * cmax),), torch.float32)     # slab partials + per-(image, channel) coefficients
         self.x_nchw = self.alloc((self.N, self.cin, self.H, self.W), torch.float32)
         self.y_nchw = self.alloc((self.N, self.cout, self.H, self.W), torch.float32)
 

@@ -187,7 +187,7 @@ def test_groupnorm_fwd_bwd(dt, C0, C1, HW, silu):
     s1 = _up(xh[..., C0:], dt) if C1 else None
     out = torch.empty(N, HW, C, device=dev, dtype=s0.dtype)
     stats = torch.empty(N, G, 2, device=dev)
-    ws = torch.empty(N, G, 2, device=dev)
+    ws = torch.empty(N * (64 * G + 4 * C), device=dev)
     gd, bd = gamma.detach().to(dev), beta.detach().to(dev)
     ops.groupnorm_fwd(DT[dt], s0, C0, s1, C1, N, HW, gd, bd, silu, out, stats, ws)
     torch.cuda.synchronize()
