@@ -84,8 +84,13 @@ typedef struct mdm_gemm_desc {
     int32_t rv_ld, rows_per_img;
     const void* resid;          /* [M][ldr] or NULL (residual add, unet6.py:333,362) */
     int32_t ldr;
-    int32_t splitk;             /* layout 2 only: >1 => fp32 atomic accumulation into D0 */
+    int32_t splitk;             /* reduction split over grid z (0 = choose; conv layouts 0/1 never split) */
     int64_t dtap;               /* layout 2 + conv: D0 offset per tap */
+    /* split-K workspace (optional).  With it, every split writes its fp32 partial tile with plain
+     * stores into ws[split][tap|batch][M][N] and a second kernel sums the splits into D0 -- float
+     * atomics from dozens of workgroups into one tile serialise at the memory side.  Without it
+     * (or when D0 is not a dense [tap|batch][M][N] block) split-K falls back to fp32 atomics. */
+    void* ws; int64_t ws_bytes;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);

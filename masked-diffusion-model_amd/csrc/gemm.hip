@@ -104,7 +104,7 @@ __device__ __forceinline__ const T* gather_ptr(const mdm_gemm_desc& d, const Row
     return reinterpret_cast<const T*>(d.src1) + spix * d.ld1 + (c - d.C0);
 }
 
-struct ZInfo { int batch, tap, kbeg, kend; };
+struct ZInfo { int batch, tap, kbeg, kend, ks, outer; };
 
 __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
     ZInfo z;
@@ -112,6 +112,7 @@ __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
     int zi = blockIdx.z;
     int sk = d.splitk < 1 ? 1 : d.splitk;
     int outer = zi / sk, ks = zi - outer * sk;
+    z.ks = ks; z.outer = outer;
     if (d.layout == 2 && d.conv) z.tap = outer; else z.batch = outer;
     if (sk > 1) {
         int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
@@ -140,7 +141,11 @@ __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z
     if (n < d.N0) { base = d.D0; ld = d.ldd0; col = n; acc = d.acc0; }
     else          { base = d.D1; ld = d.ldd1; col = n - d.N0; acc = d.acc1; }
     int64_t off = z.batch * d.sD + z.tap * d.dtap + (int64_t)m * ld + col;
-    if (d.splitk > 1) {
+    if (d.splitk > 1 && d.ws) {          // partial slab [split][tap|batch][M][N], plain stores; summed by splitk_reduce_kernel
+        const int nouter = gridDim.z / d.splitk;
+        float* p = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * nouter + z.outer) * ((int64_t)d.M * d.N) + (int64_t)m * d.N + n;
+        store4(p, v);
+    } else if (d.splitk > 1) {
         float* p = reinterpret_cast<float*>(base) + off;
         atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
     } else if (d.out_f32) {
@@ -198,6 +203,20 @@ template <typename T>
 __device__ __forceinline__ const T* a_col_ptr(const mdm_gemm_desc& d, const ZInfo& z, int k, int gm) {
     if (gm >= d.M || k >= z.kend) return nullptr;
     return reinterpret_cast<const T*>(d.A) + z.batch * d.sA + (int64_t)k * d.lda + gm;
+}
+
+// sums the split-K partial slabs into the dense fp32 destination (D = or += sum_s ws[s])
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splitk, int64_t total4, float* D, int acc) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(ws)[i];
+        for (int s = 1; s < splitk; ++s) {
+            float4 b = reinterpret_cast<const float4*>(ws)[(int64_t)s * total4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float4* q = reinterpret_cast<float4*>(D) + i;
+        if (acc) { float4 o = *q; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *q = a;
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -833,6 +852,8 @@ static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
 
 static int g_use_ring = []() { const char* e = getenv("MDM_NO_RING"); return (e && e[0] == '1') ? 0 : 1; }();
 static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
 
 int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
@@ -842,20 +863,31 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     if (int rc = validate(d)) return rc;
     int zouter = d.batch;
     if (d.layout == 2 && d.conv) zouter = d.KH * d.KW;
-    const bool big = d.dtype == MDM_BF16 && !g_force_small &&
-                     (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= 200 && d.N >= 128 && d.M >= 128;
+    // tile choice: 128x128 when that still yields enough workgroups; weight gradients (layout 2: small
+    // output, huge reduction, split-K supplies the parallelism) take the big tile whenever it fits.
+    const bool big = d.dtype == MDM_BF16 && !g_force_small && d.N >= 128 && d.M >= 128 &&
+                     (d.layout == 2 ? (!g_wgrad_small && d.K >= 2048) : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= 200);
     const int BM = d.dtype == MDM_F32 ? 64 : (big ? 128 : 64), BN = BM;
     const int BK = d.dtype == MDM_F32 ? 16 : 64;
     int64_t tiles = (int64_t)cdiv(d.M, BM) * cdiv(d.N, BN);
     if (d.layout == 2) {
-        if (d.splitk <= 0) {     // auto: aim at ~1024 workgroups, at least 4 k-steps each
-            int64_t want = 1024 / (tiles * zouter);
+        if (d.splitk <= 0) {     // auto: aim at ~g_wgrad_blocks workgroups, at least 4 k-steps each
+            int64_t want = (big ? g_wgrad_blocks : 4 * g_wgrad_blocks) / (tiles * zouter);
             int64_t cap = d.K / (4 * BK);
             d.splitk = (int)(want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want));
             if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
         }
     } else if (d.splitk < 1 || d.conv) {
         d.splitk = 1;
+    }
+    // slab mode needs a dense fp32 [tap|batch][M][N] destination and room for every split
+    const bool dense = d.out_f32 && d.N0 == d.N && d.ldd0 == d.N &&
+                       (d.layout == 2 && d.conv ? d.dtap == (int64_t)d.M * d.N : (zouter == 1 || d.sD == (int64_t)d.M * d.N));
+    const int64_t slab = (int64_t)zouter * d.M * d.N * 4;
+    if (d.splitk > 1 && d.ws && dense && d.ws_bytes >= slab * 2) {
+        if (d.ws_bytes < slab * d.splitk) d.splitk = (int)(d.ws_bytes / slab);
+    } else {
+        d.ws = nullptr;
     }
     MDM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
     dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * d.splitk));
@@ -874,6 +906,12 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         launch_bf16<128, 128>(d, grid, s);
     } else {
         launch_bf16<64, 64>(d, grid, s);
+    }
+    if (d.splitk > 1 && d.ws) {
+        const int64_t total4 = (int64_t)zouter * d.M * d.N / 4;
+        int64_t nb = (total4 + 255) / 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(d.ws), d.splitk, total4, reinterpret_cast<float*>(d.D0), d.acc0);
     }
     return launch_status("gemm launch");
 }

@@ -179,7 +179,8 @@ class _Conv:
         if self.fc_slot is not None:
             per, ld = n.dT_all[:, self.fc_slot:], n.fc_total
         ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
-        ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"))
+        ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"),
+                       ws=n.splitk_ws)
         s0, s1 = self.src0, self.src1
         if not s0.needs_grad:
             return
@@ -504,6 +505,9 @@ class UNet:
         self.t_in = self.alloc((self.N,), torch.float32)
         cmax = max(a.C for a in self.acts)
         self.gn_ws = self.alloc((self.N * (64 * 32 + 4 * cmax),), torch.float32)     # slab partials + per-(image, channel) coefficients
+        # split-K partial slabs of the weight-gradient contractions: room for 16 splits of the largest filter
+        wmax = max(s.g.taps * s.g.Cout * s.g.Cin for s in self.specs if isinstance(s, _Conv))
+        self.splitk_ws = self.alloc((16 * wmax,), torch.float32)
         self.x_nchw = self.alloc((self.N, self.cin, self.H, self.W), torch.float32)
         self.y_nchw = self.alloc((self.N, self.cout, self.H, self.W), torch.float32)
 

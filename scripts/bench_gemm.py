@@ -31,6 +31,7 @@ def timeit(fn, reps=20):
     _lib.load().mdm_event_record(b, st)
     ms = ctypes.c_float(); _lib.check(_lib.load().mdm_event_elapsed_ms(a, b, ctypes.byref(ms)))
     return ms.value * 1e3 / reps
+WS = torch.empty(16 * 9 * 256 * 512, device=dev) if os.environ.get("NOWS") != "1" else None
 sel = os.environ.get("SHAPES")
 if sel:
     shapes = [shapes[int(i)] for i in sel.split(",")]
@@ -54,7 +55,7 @@ for (c0, c1, co, H, k, s, ups, cnt) in shapes:
     fl = ops.conv_flops(g)
     t_f = timeit(lambda: ops.conv_fwd(1, g, x0, x1, w, b, y)) if "fwd" in PASSES else 1e9
     t_d = timeit(lambda: ops.conv_dgrad(1, g, dy, w, gx0, 0, gx1, 0)) if "dgrad" in PASSES else 1e9
-    t_w = timeit(lambda: ops.conv_wgrad(1, g, dy, x0, x1, gw)) if "wgrad" in PASSES else 1e9
+    t_w = timeit(lambda: ops.conv_wgrad(1, g, dy, x0, x1, gw, ws=WS)) if "wgrad" in PASSES else 1e9
     name = f"{c0}+{c1}->{co} @{H} k{k} s{s}{' up' if ups else ''} x{cnt}"
     print(f"{name:38s} {fl/1e9:6.2f} | {t_f:8.1f} {fl/t_f/1e6:6.1f} | {t_d:8.1f} {fl/t_d/1e6:6.1f} | {t_w:8.1f} {fl/t_w/1e6:6.1f}")
     tot["fwd"] += t_f * cnt; tot["dgrad"] += t_d * cnt; tot["wgrad"] += t_w * cnt; totf += fl * cnt

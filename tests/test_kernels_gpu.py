@@ -106,9 +106,14 @@ def test_conv_fwd_dgrad_wgrad(dt, case):
 
     # weight gradient, fp32 accumulate (+= on top of an existing value)
     gw = torch.full((K * K, Cout, C0 + C1), 0.5, device=_dev(), dtype=torch.float32)
-    ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw)
+    ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw)                       # split-K through fp32 atomics
     torch.cuda.synchronize()
     assert _relerr(gw - 0.5, _w_tap(w.grad)) < _tol(dt, 0.5 if dt == "bf16" else 1.0)
+    gw2 = torch.full((K * K, Cout, C0 + C1), 0.5, device=_dev(), dtype=torch.float32)
+    ws = torch.full((4 * gw2.numel(),), float("nan"), device=_dev())   # split-K through partial slabs + reduce
+    ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw2, splitk=3, ws=ws)
+    torch.cuda.synchronize()
+    assert _relerr(gw2 - 0.5, _w_tap(w.grad)) < _tol(dt, 0.5 if dt == "bf16" else 1.0)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
