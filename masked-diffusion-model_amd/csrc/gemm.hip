@@ -556,16 +556,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // select without a branch: p if ok else the zero page
 __device__ __forceinline__ const void* or_zero(bool ok, const void* p, const void* zero) { return ok ? p : zero; }
 
-template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV>
-__global__ __launch_bounds__(256) void gemm_ring_kernel(mdm_gemm_desc d) {
+template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
     constexpr int BK = 64;
     constexpr bool A_ROWS = (LAYOUT != 2), B_ROWS = (LAYOUT == 0);
     constexpr bool TAPMAJOR = A_ROWS && CONV;          // reduction index = (tap, channel), slab inside one tap
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int GA = A_BYTES / 1024 / 4, GB = B_BYTES / 1024 / 4, G = GA + GB;     // LDS-DMA pieces per wave per slab
+    constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;   // LDS-DMA pieces per wave per slab
     constexpr int ACPR = BM / 8, BCPR = BN / 8;                                     // chunks per row of a [64][cols] image
     constexpr int A_RPP = 64 / ACPR, B_RPP = 64 / BCPR;                             // k-rows per 1-KiB piece of such an image
-    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    constexpr int WROWS = NW / 2;                                                   // waves as WROWS x 2
+    constexpr int WM = BM / WROWS, WN = BN / 2, MI = WM / 16, NI = WN / 16;
     extern __shared__ __attribute__((aligned(1024))) char ring[];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -811,25 +812,25 @@ static int validate(const mdm_gemm_desc& d) {
     return 0;
 }
 
-template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV>
+template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV, int NW>
 static int launch_ring_one(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
     static bool configured = false;
     if (!configured) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV, NW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV>), grid, dim3(256), bytes, s, d);
+    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV, NW>), grid, dim3(64 * NW), bytes, s, d);
     return 0;
 }
-template <int BM, int BN, int NSTAGE>
+template <int BM, int BN, int NSTAGE, int NW = 4>
 static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     const bool c = d.conv != 0;
     switch (d.layout) {
-        case 0: return c ? launch_ring_one<BM, BN, 0, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 0, NSTAGE, false>(d, grid, s);
-        case 1: return c ? launch_ring_one<BM, BN, 1, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 1, NSTAGE, false>(d, grid, s);
-        default: return c ? launch_ring_one<BM, BN, 2, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 2, NSTAGE, false>(d, grid, s);
+        case 0: return c ? launch_ring_one<BM, BN, 0, NSTAGE, true, NW>(d, grid, s) : launch_ring_one<BM, BN, 0, NSTAGE, false, NW>(d, grid, s);
+        case 1: return c ? launch_ring_one<BM, BN, 1, NSTAGE, true, NW>(d, grid, s) : launch_ring_one<BM, BN, 1, NSTAGE, false, NW>(d, grid, s);
+        default: return c ? launch_ring_one<BM, BN, 2, NSTAGE, true, NW>(d, grid, s) : launch_ring_one<BM, BN, 2, NSTAGE, false, NW>(d, grid, s);
     }
 }
 
@@ -854,6 +855,9 @@ static int g_use_ring = []() { const char* e = getenv("MDM_NO_RING"); return (e 
 static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
+static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
+static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
+static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
 
 int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
@@ -899,8 +903,10 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
     } else if (g_use_ring && ring_eligible(d)) {
-        int rc = big ? launch_ring<128, 128, 3>(d, grid, s)
-                     : (g_stages64 == 3 ? launch_ring<64, 64, 3>(d, grid, s) : launch_ring<64, 64, 4>(d, grid, s));
+        int rc = big ? (g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
+                                         : launch_ring<128, 128, 3>(d, grid, s))
+                     : (g_small_waves == 8 ? launch_ring<64, 64, 4, 8>(d, grid, s)
+                        : (g_stages64 == 3 ? launch_ring<64, 64, 3>(d, grid, s) : launch_ring<64, 64, 4>(d, grid, s)));
         if (rc) return rc;
     } else if (big) {
         launch_bf16<128, 128>(d, grid, s);
@@ -919,5 +925,5 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
 }  // namespace mdm
 
 extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
-    return mdm::gemm_launch(desc_host, reinterpret_cast<hipStream_t>(stream));
+    return mdm::gemm_launch(desc_host, mdm::pick_stream(stream));
 }

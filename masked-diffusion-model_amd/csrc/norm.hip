@@ -432,7 +432,7 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
 
 // ws layout: [N][nblk][G][2] slab partials (nblk <= GN_MAX_SLABS), then [N][C] float4 coefficient slots
 static inline int gn_slabs(int P, int ppp) {
-    int nb = cdiv(P, 8 * ppp);                    // ~8 passes per workgroup
+    int nb = cdiv(P, 8 * ppp);                    // ~8 passes per workgroup (measured: 2 passes = 4x the workgroups is slower)
     return nb < 1 ? 1 : (nb > GN_MAX_SLABS ? GN_MAX_SLABS : nb);
 }
 extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
@@ -506,7 +506,7 @@ extern "C" int mdm_colsum(int dtype, const void* dY, int N, int P, int C, float*
                           void* stream) {
     MDM_REQUIRE(C % 8 == 0 && N > 0 && P > 0, "colsum: bad shape");
     dim3 grid(cdiv(C, 64), N);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dY, P, C, per_img, ld, acc_img, dbias));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, pick_stream(stream), (const T*)dY, P, C, per_img, ld, acc_img, dbias));
     return launch_status("colsum");
 }
 

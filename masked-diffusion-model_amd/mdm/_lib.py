@@ -61,6 +61,9 @@ _PROTOS = {
     "mdm_adamw_ema": ([vp, vp, vp, vp, vp, vp, i64, vp, vp, f32, f32, vp], i32),
     "mdm_cast_bf16": ([vp, vp, i64, vp], i32),
     "mdm_fill_f32": ([vp, f32, i64, vp], i32),
+    "mdm_fork": ([vp], i32),
+    "mdm_side_end": ([vp], i32),
+    "mdm_join": ([vp], i32),
     "mdm_graph_begin": ([vp], i32),
     "mdm_graph_end": ([vp, C.POINTER(vp)], i32),
     "mdm_graph_launch": ([vp, vp], i32),
@@ -143,6 +146,8 @@ class Recording:
         lib = load()
         pairs = []
         for i, (name, fn, args) in enumerate(self.calls):
+            if name in ("mdm_fork", "mdm_side_end", "mdm_join"):
+                continue            # timed replay is serial on `st`, so the event pairs bracket every launch
             if pick(i, name):
                 a, b = vp(), vp()
                 check(lib.mdm_event_create(C.byref(a))); check(lib.mdm_event_create(C.byref(b)))
