@@ -98,14 +98,14 @@ int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)
  * x = concat(src0[C0], src1[C1]) along channels, NHWC, P = H*W pixels per image.
- * stats: [N][G][2] fp32 (mean, rstd).  ws: fp32 scratch of N*(64*G + 4*(C0+C1)) floats, 16-byte aligned
- * (per-workgroup partial sums, then per-(image, channel) coefficients); fully written by the call.
+ * stats: [N][G][2] fp32 (mean, rstd).  One kernel per call (two passes over an L2-resident slice);
+ * `ws` is unused and may be NULL (kept for ABI stability).
  * ------------------------------------------------------------------------- */
 int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1,
                       int N, int P, int G, float eps, const float* gamma, const float* beta,
                       int silu, void* y, float* stats, float* ws, void* stream);
 /* dx -> dst0/dst1 (channel split like the sources), acc flags add into them;
- * dgamma/dbeta are ACCUMULATED (fp32 atomics).  ws: scratch sized as for the forward. */
+ * dgamma/dbeta are ACCUMULATED (one fp32 atomic per channel per image).  `ws` unused. */
 int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1,
                       int N, int P, int G, const float* gamma, const float* beta, int silu,
                       const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,

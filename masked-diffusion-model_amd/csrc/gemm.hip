@@ -856,6 +856,7 @@ static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); ret
 static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
 static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
+static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES"); return e ? atoi(e) : 200; }();
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
@@ -870,7 +871,7 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     // tile choice: 128x128 when that still yields enough workgroups; weight gradients (layout 2: small
     // output, huge reduction, split-K supplies the parallelism) take the big tile whenever it fits.
     const bool big = d.dtype == MDM_BF16 && !g_force_small && d.N >= 128 && d.M >= 128 &&
-                     (d.layout == 2 ? (!g_wgrad_small && d.K >= 2048) : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= 200);
+                     (d.layout == 2 ? (!g_wgrad_small && d.K >= 2048) : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= g_big_min_tiles);
     const int BM = d.dtype == MDM_F32 ? 64 : (big ? 128 : 64), BN = BM;
     const int BK = d.dtype == MDM_F32 ? 16 : 64;
     int64_t tiles = (int64_t)cdiv(d.M, BM) * cdiv(d.N, BN);
@@ -903,7 +904,7 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
     } else if (g_use_ring && ring_eligible(d)) {
-        int rc = big ? (g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
+        int rc = big ? (g_big_waves == 16 ? launch_ring<128, 128, 3, 16>(d, grid, s) : g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
                                          : launch_ring<128, 128, 3>(d, grid, s))
                      : (g_small_waves == 8 ? launch_ring<64, 64, 4, 8>(d, grid, s)
                         : (g_stages64 == 3 ? launch_ring<64, 64, 3>(d, grid, s) : launch_ring<64, 64, 4>(d, grid, s)));

@@ -9,251 +9,211 @@
 
 namespace mdm {
 
-// Thread mapping used by the four GroupNorm kernels: a workgroup owns one image and a
-// slab of pixels; thread t always handles the same 8-channel vector (t % VPP), so its
-// per-channel partial sums live in registers for the whole slab.
-struct GnGeom {
-    int C0, C1, C, VPP, lanes_used, pix_per_pass, cpg;
-};
-__device__ __forceinline__ GnGeom gn_geom(int C0, int C1, int G) {
-    GnGeom g;
-    g.C0 = C0; g.C1 = C1; g.C = C0 + C1;
-    g.VPP = g.C / 8;
-    g.pix_per_pass = 256 / g.VPP;
-    if (g.pix_per_pass < 1) g.pix_per_pass = 1;
-    g.lanes_used = g.VPP * g.pix_per_pass;
-    g.cpg = g.C / G;
-    return g;
-}
-
+// GroupNorm is ONE kernel per direction.  A workgroup owns one image and a block of CBLK channels
+// made of whole groups (CBLK = multiple of lcm(C/G, 8), >= 32): pass 1 streams its [P][CBLK] slice
+// once for the statistics (lane = fixed 8-channel vector, so per-channel partials stay in registers;
+// pixel lanes meet in LDS), pass 2 re-reads the slice (64 KB for the largest unet6 tensor: L2-resident)
+// and applies.  No scratch buffers, no zeroing, no atomics on the statistics.
 template <typename T>
 __device__ __forceinline__ const T* src_ptr(const T* s0, const T* s1, int C0, int C1, int64_t pix, int c) {
     return c < C0 ? s0 + pix * C0 + c : s1 + pix * C1 + (c - C0);
 }
-
-constexpr int GN_MAX_SLABS = 32;   // workgroups per image at most (bounds the partial-sum scratch)
-
-// ---- forward pass 1: per (image, group) SHIFTED sums  sum(x-K), sum((x-K)^2) -> ws[N][G][2]
-// K = the group's first element of that image.  Shifting removes the cancellation of
-// E[x^2]-mean^2 and makes constant feature maps (a fully degraded, all-zero input image gives
-// them) come out with variance exactly 0 and mean exactly K, as the reference's two-pass
-// group_norm does.
+// K = the group's first element of that image.  Shifting the sums by it removes the cancellation of
+// E[x^2]-mean^2 and makes constant feature maps (a fully degraded, all-zero input image gives them)
+// come out with variance exactly 0 and mean exactly K, as the reference's two-pass group_norm does.
 template <typename T>
 __device__ __forceinline__ float gn_pivot(const T* s0, const T* s1, int C0, int C1, int64_t img_pix0, int grp, int cpg) {
     return Elem<T>::ld(src_ptr(s0, s1, C0, C1, img_pix0, grp * cpg));
 }
+#define F8_TO_ARR(v) {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w}
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, float* ws) {
-    const GnGeom g = gn_geom(C0, C1, G);
-    __shared__ float red[2 * 64];      // G <= 64
-    const int t = threadIdx.x, img = blockIdx.y;
-    if (t < 2 * G) red[t] = 0.f;
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
+                                                     float eps, const float* gamma, const float* beta, int silu, T* y,
+                                                     float* stats) {
+    const int C = C0 + C1, cpg = C / G;
+    const int VB = CBLK / 8, PL = 256 / VB;
+    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
+    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const bool on = t < VB * PL && c < C;
+    __shared__ float gsum[2 * 64], gmean[64], grstd[64];
+    if (t < 2 * ng) gsum[t] = 0.f;
     __syncthreads();
-    if (t < g.lanes_used) {
-        const int v = t % g.VPP, c = v * 8;
+    const int64_t base = (int64_t)img * P;
+    if (on) {
         float s[8] = {}, q[8] = {}, K[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, (c + e) / g.cpg, g.cpg);
-        const int span = (P + gridDim.x - 1) / gridDim.x;     // pixels per workgroup
-        const int p_beg = blockIdx.x * span;
-        const int p_end = min(P, p_beg + span);
+        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, (c + e) / cpg, cpg);
         auto add = [&](const float8& x) {
-            float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
+            float xv[8] = F8_TO_ARR(x);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; s[e] += dlt; q[e] = fmaf(dlt, dlt, q[e]); }
         };
-        const int st = g.pix_per_pass;
-        int p = p_beg + t / g.VPP;
-        const int64_t base = (int64_t)img * P;
-        for (; p + 3 * st < p_end; p += 4 * st) {          // four independent 16-byte loads in flight per lane
+        int p = lane;
+        for (; p + 3 * PL < P; p += 4 * PL) {          // four independent 16-byte loads in flight per lane
             float8 x0 = load8(src_ptr(s0, s1, C0, C1, base + p, c));
-            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + st, c));
-            float8 x2 = load8(src_ptr(s0, s1, C0, C1, base + p + 2 * st, c));
-            float8 x3 = load8(src_ptr(s0, s1, C0, C1, base + p + 3 * st, c));
+            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + PL, c));
+            float8 x2 = load8(src_ptr(s0, s1, C0, C1, base + p + 2 * PL, c));
+            float8 x3 = load8(src_ptr(s0, s1, C0, C1, base + p + 3 * PL, c));
             add(x0); add(x1); add(x2); add(x3);
         }
-        for (; p < p_end; p += st) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)));
+        for (; p < P; p += PL) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / g.cpg;
-            atomicAdd(&red[2 * grp], s[e]);
-            atomicAdd(&red[2 * grp + 1], q[e]);
+            int gl = (c + e) / cpg - g0;
+            atomicAdd(&gsum[2 * gl], s[e]);
+            atomicAdd(&gsum[2 * gl + 1], q[e]);
         }
     }
     __syncthreads();
-    if (t < 2 * G) ws[((int64_t)img * gridDim.x + blockIdx.x) * 2 * G + t] = red[t];     // partial of this slab
+    if (t < ng && (g0 + t) < G) {
+        const float inv_cnt = 1.f / ((float)cpg * (float)P);
+        float K = gn_pivot(s0, s1, C0, C1, base, g0 + t, cpg);
+        float md = gsum[2 * t] * inv_cnt;
+        float var = fmaxf(gsum[2 * t + 1] * inv_cnt - md * md, 0.f);
+        float mean = K + md, rstd = rsqrtf(var + eps);
+        gmean[t] = mean; grstd[t] = rstd;
+        stats[((int64_t)img * G + g0 + t) * 2] = mean;
+        stats[((int64_t)img * G + g0 + t) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    if (on) {
+        float m[8], a[8], bt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int gl = (c + e) / cpg - g0;
+            m[e] = gmean[gl]; a[e] = grstd[gl] * gamma[c + e]; bt[e] = beta[c + e];
+        }
+        auto put = [&](int p, const float8& x) {
+            float xv[8] = F8_TO_ARR(x);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = fmaf(xv[e] - m[e], a[e], bt[e]);     // (x - mean) stays exact
+                if (silu) o[e] = silu_f(o[e]);
+            }
+            float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+            store8(y + (base + p) * C + c, r);
+        };
+        int p = lane;
+        for (; p + 3 * PL < P; p += 4 * PL) {
+            float8 x0 = load8(src_ptr(s0, s1, C0, C1, base + p, c));
+            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + PL, c));
+            float8 x2 = load8(src_ptr(s0, s1, C0, C1, base + p + 2 * PL, c));
+            float8 x3 = load8(src_ptr(s0, s1, C0, C1, base + p + 3 * PL, c));
+            put(p, x0); put(p + PL, x1); put(p + 2 * PL, x2); put(p + 3 * PL, x3);
+        }
+        for (; p < P; p += PL) put(p, load8(src_ptr(s0, s1, C0, C1, base + p, c)));
+    }
 }
 
-// per (image, channel): sum the slab partials of the channel's group, finish mean / rstd (group
-// leader also stores them in `stats` for the backward), emit {mean, rstd*gamma} so the streaming
-// pass does two vector loads instead of per-element look-ups.  y = (x-mean)*a + beta keeps x-mean exact.
+// backward: dx = rstd*gamma*g - rstd*(s1 + xhat*s2)/cnt with g = dy * act'(xhat*gamma + beta),
+// s1 = sum(g*gamma), s2 = sum(g*gamma*xhat) per (image, group); dgamma += sum g*xhat, dbeta += sum g.
 template <typename T>
-__global__ void gn_coef_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, const float* ws, int nblk,
-                               const float* gamma, float inv_cnt, float eps, float* stats, float2* coef, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;      // over N*C
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
+                                                     const float* gamma, const float* beta, int silu, const T* dy,
+                                                     const float* stats, T* d0, int acc0, T* d1, int acc1,
+                                                     float* dgamma, float* dbeta) {
     const int C = C0 + C1, cpg = C / G;
-    int img = i / C, c = i - img * C, grp = c / cpg;
-    float sd = 0.f, sq = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float* p = ws + ((int64_t)img * nblk + b) * 2 * G + 2 * grp;
-        sd += p[0]; sq += p[1];
-    }
-    float K = gn_pivot(s0, s1, C0, C1, (int64_t)img * P, grp, cpg);
-    float md = sd * inv_cnt;
-    float var = fmaxf(sq * inv_cnt - md * md, 0.f);
-    float mean = K + md, rstd = rsqrtf(var + eps);
-    if (c == grp * cpg) { stats[((int64_t)img * G + grp) * 2] = mean; stats[((int64_t)img * G + grp) * 2 + 1] = rstd; }
-    coef[i] = make_float2(mean, rstd * gamma[c]);
-}
-// backward: {mean, rstd, rstd*s1/cnt, rstd*s2/cnt}
-__global__ void gn_bwd_coef_kernel(const float* stats, const float* ws, int nblk, int C, int G, float inv_cnt, float4* coef, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int img = i / C, c = i - img * C, grp = c / (C / G);
-    float a1 = 0.f, a2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float* p = ws + ((int64_t)img * nblk + b) * 2 * G + 2 * grp;
-        a1 += p[0]; a2 += p[1];
-    }
-    int64_t si = ((int64_t)img * G + grp) * 2;
-    float mean = stats[si], rstd = stats[si + 1];
-    coef[i] = make_float4(mean, rstd, rstd * a1 * inv_cnt, rstd * a2 * inv_cnt);
-}
-
-// ---- forward pass 2: y = act((x - mean) * (rstd*gamma) + beta)
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* s0, int C0, const T* s1, int C1, int P,
-                                                       const float2* coef, const float* beta, int silu, T* y, int64_t total_vec) {
-    const int C = C0 + C1, VPP = C / 8;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t pix = i / VPP;
-        int c = (int)(i - pix * VPP) * 8;
-        int img = (int)(pix / P);
-        float8 x = load8(src_ptr(s0, s1, C0, C1, pix, c));
-        const float4* cf = reinterpret_cast<const float4*>(coef + (int64_t)img * C + c);     // 8 x {mean, a}
-        float4 c01 = cf[0], c23 = cf[1], c45 = cf[2], c67 = cf[3];
-        float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
-        float o[8];
-        o[0] = fmaf(x.lo.x - c01.x, c01.y, b0.x); o[1] = fmaf(x.lo.y - c01.z, c01.w, b0.y);
-        o[2] = fmaf(x.lo.z - c23.x, c23.y, b0.z); o[3] = fmaf(x.lo.w - c23.z, c23.w, b0.w);
-        o[4] = fmaf(x.hi.x - c45.x, c45.y, b1.x); o[5] = fmaf(x.hi.y - c45.z, c45.w, b1.y);
-        o[6] = fmaf(x.hi.z - c67.x, c67.y, b1.z); o[7] = fmaf(x.hi.w - c67.z, c67.w, b1.w);
-        if (silu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = silu_f(o[e]);
-        }
-        float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-        store8(y + pix * C + c, r);
-    }
-}
-
-// ---- backward pass 1: per (image, group) s1 = sum g*gamma, s2 = sum g*gamma*xhat; dgamma/dbeta
-template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G,
-                                                           const float* gamma, const float* beta, int silu,
-                                                           const T* dy, const float* stats, float* ws,
-                                                           float* dgamma, float* dbeta) {
-    const GnGeom g = gn_geom(C0, C1, G);
-    __shared__ float red[2 * 64];
-    extern __shared__ float chan[];          // [2][C]: per-channel dgamma / dbeta partials of this workgroup
-    const int t = threadIdx.x, img = blockIdx.y;
-    if (t < 2 * G) red[t] = 0.f;
-    for (int i = t; i < 2 * g.C; i += 256) chan[i] = 0.f;
+    const int VB = CBLK / 8, PL = 256 / VB;
+    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
+    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const bool on = t < VB * PL && c < C;
+    __shared__ float gsum[2 * 64];
+    __shared__ float chan[2 * 64];           // per-channel dgamma / dbeta of this workgroup (CBLK <= 64)
+    if (t < 2 * ng) gsum[t] = 0.f;
+    if (t < 2 * CBLK) chan[t] = 0.f;
     __syncthreads();
-    if (t < g.lanes_used) {
-        const int v = t % g.VPP, c = v * 8;
-        float ga[8], be[8], mean[8], rstd[8];
+    const int64_t base = (int64_t)img * P;
+    float ga[8], be[8], mean[8], rstd[8];
+    if (on) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / g.cpg;
+            int grp = (c + e) / cpg;
             ga[e] = gamma[c + e]; be[e] = beta[c + e];
             mean[e] = stats[((int64_t)img * G + grp) * 2]; rstd[e] = stats[((int64_t)img * G + grp) * 2 + 1];
         }
         float a1[8] = {}, a2[8] = {}, dg[8] = {}, db[8] = {};
-        const int span = (P + gridDim.x - 1) / gridDim.x;
-        const int p_beg = blockIdx.x * span;
-        const int p_end = min(P, p_beg + span);
         auto add = [&](const float8& x, const float8& d) {
-            float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
-            float dv[8] = {d.lo.x, d.lo.y, d.lo.z, d.lo.w, d.hi.x, d.hi.y, d.hi.z, d.hi.w};
+            float xv[8] = F8_TO_ARR(x);
+            float dv[8] = F8_TO_ARR(d);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float xh = (xv[e] - mean[e]) * rstd[e];
                 float gz = dv[e];
-                if (silu) gz *= silu_grad_f(xh * ga[e] + be[e]);
+                if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
                 dg[e] = fmaf(gz, xh, dg[e]); db[e] += gz;
                 float gg = gz * ga[e];
                 a1[e] += gg; a2[e] = fmaf(gg, xh, a2[e]);
             }
         };
-        const int st = g.pix_per_pass;
-        int p = p_beg + t / g.VPP;
-        const int64_t base = (int64_t)img * P;
-        for (; p + st < p_end; p += 2 * st) {              // two pixel rows (four 16-byte loads) in flight per lane
+        int p = lane;
+        for (; p + PL < P; p += 2 * PL) {
             float8 x0 = load8(src_ptr(s0, s1, C0, C1, base + p, c));
-            float8 d0 = load8(dy + (base + p) * g.C + c);
-            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + st, c));
-            float8 d1 = load8(dy + (base + p + st) * g.C + c);
-            add(x0, d0); add(x1, d1);
+            float8 e0 = load8(dy + (base + p) * C + c);
+            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + PL, c));
+            float8 e1 = load8(dy + (base + p + PL) * C + c);
+            add(x0, e0); add(x1, e1);
         }
-        for (; p < p_end; p += st) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * g.C + c));
+        for (; p < P; p += PL) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * C + c));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / g.cpg;
-            atomicAdd(&red[2 * grp], a1[e]);
-            atomicAdd(&red[2 * grp + 1], a2[e]);
-            atomicAdd(&chan[c + e], dg[e]);                 // LDS atomics: the pixel lanes of one channel meet here
-            atomicAdd(&chan[g.C + c + e], db[e]);
+            int gl = (c + e) / cpg - g0;
+            atomicAdd(&gsum[2 * gl], a1[e]);
+            atomicAdd(&gsum[2 * gl + 1], a2[e]);
+            atomicAdd(&chan[v * 8 + e], dg[e]);
+            atomicAdd(&chan[CBLK + v * 8 + e], db[e]);
         }
     }
     __syncthreads();
-    if (t < 2 * G) ws[((int64_t)img * gridDim.x + blockIdx.x) * 2 * G + t] = red[t];
-    for (int i = t; i < g.C; i += 256) {                    // one global atomic per channel per workgroup
-        atomicAdd(&dgamma[i], chan[i]);
-        atomicAdd(&dbeta[i], chan[g.C + i]);
+    if (t < CBLK && cb + t < C) {            // one global atomic per channel per workgroup (= per image)
+        atomicAdd(&dgamma[cb + t], chan[t]);
+        atomicAdd(&dbeta[cb + t], chan[CBLK + t]);
     }
-}
-
-// ---- backward pass 2: dx = rstd*gamma*g - (rstd*s1/cnt + xhat*rstd*s2/cnt),  g = dy * act'(xhat*gamma + beta)
-template <typename T>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* s0, int C0, const T* s1, int C1, int P,
-                                                           const float* gamma, const float* beta, int silu,
-                                                           const T* dy, const float4* coef,
-                                                           T* d0, int acc0, T* d1, int acc1, int64_t total_vec) {
-    const int C = C0 + C1, VPP = C / 8;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t pix = i / VPP;
-        int c = (int)(i - pix * VPP) * 8;
-        int img = (int)(pix / P);
-        float8 x = load8(src_ptr(s0, s1, C0, C1, pix, c));
-        float8 d = load8(dy + pix * C + c);
-        float xv[8] = {x.lo.x, x.lo.y, x.lo.z, x.lo.w, x.hi.x, x.hi.y, x.hi.z, x.hi.w};
-        float dv[8] = {d.lo.x, d.lo.y, d.lo.z, d.lo.w, d.hi.x, d.hi.y, d.hi.z, d.hi.w};
-        const float4* cf = coef + (int64_t)img * C + c;
-        float4 g0 = *reinterpret_cast<const float4*>(gamma + c), g1 = *reinterpret_cast<const float4*>(gamma + c + 4);
-        float4 b0 = *reinterpret_cast<const float4*>(beta + c), b1 = *reinterpret_cast<const float4*>(beta + c + 4);
-        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float o[8];
+    if (on) {
+        const float inv_cnt = 1.f / ((float)cpg * (float)P);
+        float k1[8], k2[8], ag[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float4 k = cf[e];                          // mean, rstd, rstd*s1/cnt, rstd*s2/cnt
-            float xh = (xv[e] - k.x) * k.y;
-            float gz = dv[e];
-            if (silu) gz *= silu_grad_f(fmaf(xh, gv[e], bv[e]));
-            o[e] = k.y * gv[e] * gz - fmaf(xh, k.w, k.z);
+            int gl = (c + e) / cpg - g0;
+            k1[e] = rstd[e] * gsum[2 * gl] * inv_cnt;
+            k2[e] = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
+            ag[e] = rstd[e] * ga[e];
         }
-        T* dst; int acc;
-        if (c < C0) { dst = d0 + pix * C0 + c; acc = acc0; } else { dst = d1 + pix * C1 + (c - C0); acc = acc1; }
-        if (acc) {
-            float8 old = load8(dst);
-            o[0] += old.lo.x; o[1] += old.lo.y; o[2] += old.lo.z; o[3] += old.lo.w;
-            o[4] += old.hi.x; o[5] += old.hi.y; o[6] += old.hi.z; o[7] += old.hi.w;
+        T* dst; int acc, cc, CS;
+        if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
+        auto put = [&](int p, const float8& x, const float8& d) {
+            float xv[8] = F8_TO_ARR(x);
+            float dv[8] = F8_TO_ARR(d);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float xh = (xv[e] - mean[e]) * rstd[e];
+                float gz = dv[e];
+                if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
+                o[e] = ag[e] * gz - fmaf(xh, k2[e], k1[e]);
+            }
+            T* q = dst + (base + p) * CS + cc;
+            if (acc) {
+                float8 old = load8(q);
+                float ov[8] = F8_TO_ARR(old);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += ov[e];
+            }
+            float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+            store8(q, r);
+        };
+        int p = lane;
+        for (; p + PL < P; p += 2 * PL) {
+            float8 x0 = load8(src_ptr(s0, s1, C0, C1, base + p, c));
+            float8 e0 = load8(dy + (base + p) * C + c);
+            float8 x1 = load8(src_ptr(s0, s1, C0, C1, base + p + PL, c));
+            float8 e1 = load8(dy + (base + p + PL) * C + c);
+            put(p, x0, e0); put(p + PL, x1, e1);
         }
-        float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-        store8(dst, r);
+        for (; p < P; p += PL) put(p, load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * C + c));
     }
 }
 
@@ -430,28 +390,24 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
     return 0;
 }
 
-// ws layout: [N][nblk][G][2] slab partials (nblk <= GN_MAX_SLABS), then [N][C] float4 coefficient slots
-static inline int gn_slabs(int P, int ppp) {
-    int nb = cdiv(P, 8 * ppp);                    // ~8 passes per workgroup (measured: 2 passes = 4x the workgroups is slower)
-    return nb < 1 ? 1 : (nb > GN_MAX_SLABS ? GN_MAX_SLABS : nb);
+// channels per workgroup: whole groups, whole 16-byte vectors, at least 32 channels
+static int gn_cblk(int C, int G) {
+    int cpg = C / G, l = cpg;
+    while (l % 8) l += cpg;            // lcm(cpg, 8)
+    int cb = l;
+    while (cb < 32) cb += l;
+    return cb > C ? C : cb;
 }
 extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                  float eps, const float* gamma, const float* beta, int silu, void* y, float* stats,
                                  float* ws, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const int C = C0 + C1, ppp = (256 / (C / 8)) < 1 ? 1 : 256 / (C / 8);
-    const int nblk = gn_slabs(P, ppp);
-    dim3 g1(nblk, N);
-    const int64_t tv = (int64_t)N * P * (C / 8);
-    float2* coef = reinterpret_cast<float2*>(ws + (int64_t)N * GN_MAX_SLABS * 2 * G);
-    DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((gn_stats_kernel<T>), g1, dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1, P, G, ws);
-        hipLaunchKernelGGL((gn_coef_kernel<T>), dim3(cdiv(N * C, 256)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1, P, G,
-                           ws, nblk, gamma, 1.f / ((float)(C / G) * (float)P), eps, stats, coef, N * C);
-        hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1, C1,
-                           P, coef, beta, silu, (T*)y, tv);
-    });
+    (void)ws;
+    const int C = C0 + C1, cblk = gn_cblk(C, G);
+    MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
+    dim3 grid(cdiv(C, cblk), N);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gn_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
+                                         (const T*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (T*)y, stats));
     return launch_status("groupnorm_fwd");
 }
 
@@ -460,20 +416,13 @@ extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void
                                  void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta, float* ws,
                                  void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const int C = C0 + C1, ppp = (256 / (C / 8)) < 1 ? 1 : 256 / (C / 8);
-    const int nblk = gn_slabs(P, ppp);
-    dim3 g1(nblk, N);
-    const int64_t tv = (int64_t)N * P * (C / 8);
-    float4* coef = reinterpret_cast<float4*>(ws + (int64_t)N * GN_MAX_SLABS * 2 * G);
-    DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((gn_bwd_stats_kernel<T>), g1, dim3(256), 2 * C * sizeof(float), s, (const T*)src0, C0, (const T*)src1, C1, P, G, gamma,
-                           beta, silu, (const T*)dy, stats, ws, dgamma, dbeta);
-        hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, stats, ws, nblk, C, G,
-                           1.f / ((float)(C / G) * (float)P), coef, N * C);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), dim3(stream_grid(tv)), dim3(256), 0, s, (const T*)src0, C0, (const T*)src1,
-                           C1, P, gamma, beta, silu, (const T*)dy, coef, (T*)dst0, acc0, (T*)dst1, acc1, tv);
-    });
+    (void)ws;
+    const int C = C0 + C1, cblk = gn_cblk(C, G);
+    MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
+    dim3 grid(cdiv(C, cblk), N);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
+                                         (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0, acc0,
+                                         (T*)dst1, acc1, dgamma, dbeta));
     return launch_status("groupnorm_bwd");
 }
 
