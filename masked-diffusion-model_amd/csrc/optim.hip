@@ -47,6 +47,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
+// Transposed bf16 shadow of the conv filters: master fp32 [tap][Cout][Cin] -> bf16 [tap][Cin][Cout], so the
+// data-gradient contraction reads its weights k-contiguous like the forward does.  One workgroup per
+// 32x32 tile of one tap of one layer; `tiles` = {src offset of the tap matrix, Cout, Cin, row0, col0} x ntiles.
+__global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* P, bf16_t* PT, const int64_t* tiles, int ntiles) {
+    __shared__ float tile[32][33];
+    const int64_t* e = tiles + (int64_t)blockIdx.x * 5;
+    const int64_t off = e[0];
+    const int Cout = (int)e[1], Cin = (int)e[2], r0 = (int)e[3], c0 = (int)e[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < Cout && c < Cin) ? P[off + (int64_t)r * Cin + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;                        // write PT[c][r]
+        if (c < Cin && r < Cout) PT[off + (int64_t)c * Cout + r] = f2bf(tile[tx][ty + 8 * i]);
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
 }
@@ -73,6 +95,11 @@ extern "C" int mdm_adamw_ema(float* p, const float* g, float* m, float* v, float
     hipLaunchKernelGGL(adamw_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)shadow_bf16, n, hp,
                        sqnorm, max_norm, gmul);
     return launch_status("adamw");
+}
+extern "C" int mdm_transpose_shadow(const float* P, void* PT, const int64_t* tiles, int ntiles, void* stream) {
+    MDM_REQUIRE(P && PT && tiles && ntiles > 0, "transpose_shadow: bad arguments");
+    hipLaunchKernelGGL(transpose_shadow_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, P, (bf16_t*)PT, tiles, ntiles);
+    return launch_status("transpose_shadow");
 }
 extern "C" int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);

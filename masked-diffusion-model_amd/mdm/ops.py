@@ -80,6 +80,16 @@ def conv_dgrad(dt, g: ConvGeom, dy, w, dst0, acc0, dst1=None, acc1=0):
               D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g))
 
 
+def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0):
+    """Same gradient as conv_dgrad but with per-tap TRANSPOSED filters wT[tap][Cin][Cout]: both operands
+    are k-contiguous (layout 0), the path the forward uses."""
+    _lib.gemm(dtype=dt, layout=0, M=g.N * g.VH * g.VW, N=g.Cin, K=g.taps * g.Cout,
+              conv=1, OH=g.VH, OW=g.VW, IH=g.OH, IW=g.OW, KH=g.KH, KW=g.KW, stride=g.stride,
+              pad_t=g.pad_t, pad_l=g.pad_l, transposed=1, ups=0, C0=g.Cout, C1=0, Ck=g.Cout,
+              src0=dy, src1=None, ld0=g.Cout, ld1=0, B=wT, ldb=g.Cout, wtap=g.Cout * g.Cin,
+              D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g))
+
+
 def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None):
     """dw[tap][Cout][Cin] (fp32) += sum_pixels dy x gathered input.  `ws`: fp32 split-K workspace tensor."""
     _lib.gemm(dtype=dt, layout=2, M=g.Cout, N=g.Cin, K=g.N * g.OH * g.OW,

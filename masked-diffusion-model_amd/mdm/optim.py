@@ -48,6 +48,7 @@ class AdamW:
         call("mdm_sqnorm", ptr(st.G), st.size, ptr(self.sqnorm), stream())
         call("mdm_adamw_ema", ptr(st.P), ptr(st.G), ptr(self.m), ptr(self.v), ptr(ema_buf), ptr(st.Pb), st.size,
              ptr(self.hp), ptr(self.sqnorm), float(max_norm), float(gmul), stream())
+        st.emit_transposed_shadow()
 
     def step(self, max_norm=0.0):
         self.hyper()

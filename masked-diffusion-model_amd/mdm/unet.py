@@ -77,6 +77,20 @@ class ParamStore:
         self.P = torch.zeros(self.size, device=device, dtype=torch.float32)
         self.G = torch.zeros(self.size, device=device, dtype=torch.float32)
         self.Pb = torch.zeros(self.size, device=device, dtype=torch.bfloat16) if dtype == BF16 else None
+        # second bf16 shadow with every conv filter transposed per tap ([tap][Cin][Cout]) for the data gradient
+        self.PbT = None
+        if dtype == BF16:
+            self.PbT = torch.zeros(self.size, device=device, dtype=torch.bfloat16)
+            rows = []
+            for e in self.entries.values():
+                if e.kind != "conv":
+                    continue
+                taps, co, ci = e.ishape
+                for tp in range(taps):
+                    for r0 in range(0, co, 32):
+                        for c0 in range(0, ci, 32):
+                            rows.append((e.off + tp * co * ci, co, ci, r0, c0))
+            self.tiles = torch.tensor(rows, dtype=torch.int64, device=device)
 
     def f(self, name):          # fp32 master view
         e = self.entries[name]
@@ -92,9 +106,20 @@ class ParamStore:
         e = self.entries[name]
         return self.Pb[e.off:e.off + e.n].view(e.ishape)
 
+    def wT(self, name):         # per-tap transposed bf16 filter [tap][Cin][Cout]
+        e = self.entries[name]
+        taps, co, ci = e.ishape
+        return self.PbT[e.off:e.off + e.n].view(taps, ci, co)
+
+    def emit_transposed_shadow(self):
+        if self.PbT is not None:
+            _lib.call("mdm_transpose_shadow", _lib.ptr(self.P), _lib.ptr(self.PbT), _lib.ptr(self.tiles),
+                      int(self.tiles.shape[0]), _lib.stream())
+
     def sync_shadow(self):
         if self.Pb is not None:
             ops.cast_bf16(self.P, self.Pb)
+            self.emit_transposed_shadow()
 
     # -- reference state_dict interchange
     def to_internal(self, name, t):
@@ -192,15 +217,20 @@ class _Conv:
             _lib.call("mdm_side_end", _lib.stream())
         if not s0.needs_grad:
             return
+        # bf16: the filters come from the per-tap transposed shadow so both operands are k-contiguous
+        if n.dt == BF16:
+            dgrad, wmat = ops.conv_dgrad_t, st.wT(self.name + ".weight")
+        else:
+            dgrad, wmat = ops.conv_dgrad, st.w(self.name + ".weight")
         if g.ups:
             tmp = n.scratch(g.N * g.VH * g.VW * g.Cin)
-            ops.conv_dgrad(n.dt, g, dy, st.w(self.name + ".weight"), tmp, 0)
+            dgrad(n.dt, g, dy, wmat, tmp, 0)
             g0, a0 = n.grad_for_write(s0)
             ops.sumpool2(n.dt, tmp, g0, a0, g.N, g.IH, g.IW, g.Cin)
         else:
             g0, a0 = n.grad_for_write(s0)
             g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
-            ops.conv_dgrad(n.dt, g, dy, st.w(self.name + ".weight"), g0, a0, g1, a1)
+            dgrad(n.dt, g, dy, wmat, g0, a0, g1, a1)
         if fork:
             _lib.call("mdm_join", _lib.stream())
 

@@ -104,6 +104,20 @@ def test_conv_fwd_dgrad_wgrad(dt, case):
     if C1:
         assert _relerr(gx1, _nhwc(x1.grad)) < _tol(dt, 1.5)
 
+    if dt == "bf16":     # same gradient through the per-tap transposed filters (layout 0)
+        wT = _up(_w_tap(w.detach()).transpose(1, 2).contiguous(), dt)
+        hx0 = torch.zeros(N, geom.VH, geom.VW, C0, device=_dev(), dtype=d0.dtype)
+        hx1 = torch.zeros(N, geom.VH, geom.VW, C1, device=_dev(), dtype=d0.dtype) if C1 else None
+        ops.conv_dgrad_t(DT[dt], geom, dgy, wT, hx0, 0, hx1, 0)
+        if ups:
+            q0 = torch.empty(N, H, H, C0, device=_dev(), dtype=d0.dtype)
+            ops.sumpool2(DT[dt], hx0, q0, 0, N, H, H, C0)
+            hx0 = q0
+        torch.cuda.synchronize()
+        assert _relerr(hx0, _nhwc(x0.grad)) < _tol(dt, 1.5)
+        if C1:
+            assert _relerr(hx1, _nhwc(x1.grad)) < _tol(dt, 1.5)
+
     # weight gradient, fp32 accumulate (+= on top of an existing value)
     gw = torch.full((K * K, Cout, C0 + C1), 0.5, device=_dev(), dtype=torch.float32)
     ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw)                       # split-K through fp32 atomics
