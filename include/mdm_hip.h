@@ -91,6 +91,10 @@ typedef struct mdm_gemm_desc {
      * atomics from dozens of workgroups into one tile serialise at the memory side.  Without it
      * (or when D0 is not a dense [tap|batch][M][N] block) split-K falls back to fp32 atomics. */
     void* ws; int64_t ws_bytes;
+    /* layout 2, bf16: if set, dbias[m] += sum_k A[k][m] (the bias gradient of a convolution is the column
+     * sum of dY, which the weight-gradient kernel already holds as MFMA fragments: one extra MFMA against
+     * a ones-fragment per k-step in the tap-0 / first-column workgroups, fp32 atomics at the end). */
+    float* dbias;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);

@@ -725,6 +725,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient fused into the weight gradient: column sums of the A tile (= dY) as one more MFMA
+    const bool do_bias = LAYOUT == 2 && d.dbias != nullptr && z.outer == 0 && n0 == 0 && wc == 0;
+    f32x4 accb[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;      // bf16 1.0
+
     const int nk = TAPMAJOR ? d.KH * d.KW * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
     // prologue: NSTAGE-1 slabs in flight.  Slabs past the end are issued too (all-zero or harmless
     // re-reads) so that the vmcnt bookkeeping below is the same for every trip count.
@@ -753,9 +762,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (LAYOUT == 2 && do_bias) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+            }
         }
     }
     wait_vmcnt<0>();                           // the over-issued tail slabs must land before the workgroup retires
+    if (LAYOUT == 2 && do_bias && (lane >> 4) == 0) {          // every column of ones x A^T holds sum_k A[k][m]
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            int m = m0 + wr * WM + i * 16 + (lane & 15);
+            if (m < d.M) atomicAdd(&d.dbias[m], accb[i][0]);
+        }
+    }
 #undef MDM_RING_ISSUE
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -804,6 +824,7 @@ static int validate(const mdm_gemm_desc& d) {
         MDM_REQUIRE(d.lda % vec == 0 && d.ldb % vec == 0, "gemm: operand pitch must be a multiple of %d", vec);
     }
     if (d.rowvec) MDM_REQUIRE(d.rows_per_img > 0 && d.rv_ld % 4 == 0, "gemm: bad rowvec params");
+    if (d.dbias) MDM_REQUIRE(d.layout == 2 && d.dtype == MDM_BF16, "gemm: dbias is fused only into the bf16 layout-2 kernel");
     if (d.resid) MDM_REQUIRE(d.ldr % 4 == 0, "gemm: bad resid pitch");
     if (d.splitk > 1) MDM_REQUIRE(d.out_f32 || d.dtype == MDM_F32, "gemm: split-K needs an fp32 destination");
     if (d.splitk > 1 && d.layout != 2)

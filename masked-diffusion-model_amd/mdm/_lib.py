@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("src0", vp), ("src1", vp), ("ld0", i32), ("ld1", i32), ("wtap", i64),
         ("D0", vp), ("D1", vp), ("ldd0", i32), ("ldd1", i32), ("N0", i32), ("out_f32", i32), ("alpha", f32),
         ("acc0", i32), ("acc1", i32), ("bias", vp), ("rowvec", vp), ("rv_ld", i32), ("rows_per_img", i32),
-        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64),
+        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp),
     ]
 
 

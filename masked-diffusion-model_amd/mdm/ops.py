@@ -90,14 +90,15 @@ def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0):
               D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g))
 
 
-def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None):
-    """dw[tap][Cout][Cin] (fp32) += sum_pixels dy x gathered input.  `ws`: fp32 split-K workspace tensor."""
+def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None, dbias=None):
+    """dw[tap][Cout][Cin] (fp32) += sum_pixels dy x gathered input.  `ws`: fp32 split-K workspace tensor;
+    `dbias` (bf16 path only): fp32 [Cout] that also receives += column sums of dy."""
     _lib.gemm(dtype=dt, layout=2, M=g.Cout, N=g.Cin, K=g.N * g.OH * g.OW,
               conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
               pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
               src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, A=dy, lda=g.Cout,
               D0=dw, ldd0=g.Cin, N0=g.Cin, out_f32=1, acc0=1, splitk=splitk, dtap=g.Cout * g.Cin, _flops=conv_flops(g),
-              ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
+              ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0), dbias=dbias)
 
 
 def matmul(dt, layout, M, N, K, A, lda, B, ldb, D, ldd, batch=1, sA=0, sB=0, sD=0, alpha=1.0, bias=None,

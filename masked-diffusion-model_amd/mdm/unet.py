@@ -210,9 +210,11 @@ class _Conv:
         fork = n.concurrent_bwd and s0.needs_grad
         if fork:
             _lib.call("mdm_fork", _lib.stream())
-        ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
+        fuse_bias = n.dt == BF16 and self.fc_slot is None     # bias sums ride along in the weight-gradient kernel
+        if not fuse_bias:
+            ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
         ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"),
-                       ws=n.splitk_ws2 if fork else n.splitk_ws)
+                       ws=n.splitk_ws2 if fork else n.splitk_ws, dbias=st.g(self.name + ".bias") if fuse_bias else None)
         if fork:
             _lib.call("mdm_side_end", _lib.stream())
         if not s0.needs_grad:

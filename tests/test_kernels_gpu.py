@@ -125,9 +125,12 @@ def test_conv_fwd_dgrad_wgrad(dt, case):
     assert _relerr(gw - 0.5, _w_tap(w.grad)) < _tol(dt, 0.5 if dt == "bf16" else 1.0)
     gw2 = torch.full((K * K, Cout, C0 + C1), 0.5, device=_dev(), dtype=torch.float32)
     ws = torch.full((4 * gw2.numel(),), float("nan"), device=_dev())   # split-K through partial slabs + reduce
-    ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw2, splitk=3, ws=ws)
+    gb = torch.full((Cout,), 0.25, device=_dev()) if dt == "bf16" else None     # fused bias gradient (bf16 kernel)
+    ops.conv_wgrad(DT[dt], geom, dgy, d0, d1, gw2, splitk=3, ws=ws, dbias=gb)
     torch.cuda.synchronize()
     assert _relerr(gw2 - 0.5, _w_tap(w.grad)) < _tol(dt, 0.5 if dt == "bf16" else 1.0)
+    if gb is not None:
+        assert _relerr(gb - 0.25, gy.sum((0, 2, 3))) < 1e-3
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
