@@ -115,6 +115,14 @@ int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int
                       const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
                       float* dgamma, float* dbeta, float* ws, void* stream);
 
+/* Same, and the column sums of the dx it writes (dx = the complete gradient of a conv output: acc0 == 0, one
+ * source): sum_img[n*sum_ld + c] = sum_p dx (the time-embedding gradient, unet6.py:359) and
+ * sum_all[c] += sum_{n,p} dx (that conv's bias gradient).  Either may be NULL. */
+int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1,
+                           int N, int P, int G, const float* gamma, const float* beta, int silu,
+                           const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
+                           float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, void* stream);
+
 /* row softmax of S[rows][L] in place (unet6.py:320-322), and its backward
  * dS = P * (dP - sum_j dP*P) written over dP. */
 int mdm_softmax_fwd(int dtype, void* S, int rows, int L, void* stream);

@@ -114,7 +114,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
                                                      const float* gamma, const float* beta, int silu, const T* dy,
                                                      const float* stats, T* d0, int acc0, T* d1, int acc1,
-                                                     float* dgamma, float* dbeta) {
+                                                     float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
     const int img = blockIdx.y, cb = blockIdx.x * CBLK;
@@ -172,9 +172,9 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
         atomicAdd(&dgamma[cb + t], chan[t]);
         atomicAdd(&dbeta[cb + t], chan[CBLK + t]);
     }
+    float k1[8], k2[8], ag[8];
     if (on) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
-        float k1[8], k2[8], ag[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int gl = (c + e) / cpg - g0;
@@ -182,8 +182,16 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
             k2[e] = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
             ag[e] = rstd[e] * ga[e];
         }
+    }
+    if (sum_img || sum_all) {               // recycle gsum for the dx column sums once everybody has read it
+        __syncthreads();
+        if (t < 128) gsum[t] = 0.f;
+        __syncthreads();
+    }
+    if (on) {
         T* dst; int acc, cc, CS;
         if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
+        float sx[8] = {};                     // column sums of dx (bias / time-embedding gradient of the producer conv)
         auto put = [&](int p, const float8& x, const float8& d) {
             float xv[8] = F8_TO_ARR(x);
             float dv[8] = F8_TO_ARR(d);
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
                 float gz = dv[e];
                 if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
                 o[e] = ag[e] * gz - fmaf(xh, k2[e], k1[e]);
+                sx[e] += o[e];
             }
             T* q = dst + (base + p) * CS + cc;
             if (acc) {
@@ -214,6 +223,17 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
             put(p, x0, e0); put(p + PL, x1, e1);
         }
         for (; p < P; p += PL) put(p, load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * C + c));
+        if (sum_img || sum_all) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&gsum[(v * 8 + e)], sx[e]);      // gsum is free again (see barrier below)
+        }
+    }
+    if (sum_img || sum_all) {
+        __syncthreads();
+        if (t < CBLK && cb + t < C) {
+            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = gsum[t];       // one workgroup owns (image, channel)
+            if (sum_all) atomicAdd(&sum_all[cb + t], gsum[t]);
+        }
     }
 }
 
@@ -411,18 +431,31 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     return launch_status("groupnorm_fwd");
 }
 
+extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
+                                      const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
+                                      void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta,
+                                      float* sum_img, int sum_ld, float* sum_all, void* stream);
+
 extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                  const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                  void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta, float* ws,
                                  void* stream) {
+    return mdm_groupnorm_bwd_sums(dtype, src0, C0, src1, C1, N, P, G, gamma, beta, silu, dy, stats, dst0, acc0, dst1, acc1,
+                                  dgamma, dbeta, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
+                                      const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
+                                      void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta,
+                                      float* sum_img, int sum_ld, float* sum_all, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
-    (void)ws;
     const int C = C0 + C1, cblk = gn_cblk(C, G);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
+    MDM_REQUIRE(!(sum_img || sum_all) || (acc0 == 0 && C1 == 0), "groupnorm_bwd_sums: column sums need a plain (non-accumulating, single-source) dx");
     dim3 grid(cdiv(C, cblk), N);
     DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
                                          (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0, acc0,
-                                         (T*)dst1, acc1, dgamma, dbeta));
+                                         (T*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all));
     return launch_status("groupnorm_bwd");
 }
 

@@ -114,9 +114,10 @@ def groupnorm_fwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, y, stats, ws,
 
 
 def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, dst0, acc0, dst1, acc1,
-                  dgamma, dbeta, ws, G=32):
-    call("mdm_groupnorm_bwd", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
-         ptr(stats), ptr(dst0), int(acc0), ptr(dst1), int(acc1), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+                  dgamma, dbeta, ws, G=32, sum_img=None, sum_ld=0, sum_all=None):
+    call("mdm_groupnorm_bwd_sums", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
+         ptr(stats), ptr(dst0), int(acc0), ptr(dst1), int(acc1), ptr(dgamma), ptr(dbeta), ptr(sum_img), sum_ld,
+         ptr(sum_all), stream())
 
 
 def softmax_fwd(dt, S, rows, L):

@@ -211,7 +211,7 @@ class _Conv:
         if fork:
             _lib.call("mdm_fork", _lib.stream())
         fuse_bias = n.dt == BF16 and self.fc_slot is None     # bias sums ride along in the weight-gradient kernel
-        if not fuse_bias:
+        if not fuse_bias and not getattr(self, "sums_by_norm", False):
             ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
         ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"),
                        ws=n.splitk_ws2 if fork else n.splitk_ws, dbias=st.g(self.name + ".bias") if fuse_bias else None)
@@ -259,9 +259,14 @@ class _Norm:
         assert self.out.grad_written, self.name
         g0, a0 = n.grad_for_write(s0)
         g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
+        sums = {}
+        prod = getattr(self, "producer", None)      # conv1 of a ResidualBlock: this dx is its complete dY
+        if prod is not None and a0 == 0 and s1 is None:
+            sums = dict(sum_img=n.dT_all[:, prod.fc_slot:], sum_ld=n.fc_total, sum_all=st.g(prod.name + ".bias"))
+            prod.sums_by_norm = True
         ops.groupnorm_bwd(n.dt, s0.data, s0.C, s1.data if s1 else None, s1.C if s1 else 0, s0.N, s0.P,
                           st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, self.out.grad, self.stats,
-                          g0, a0, g1, a1, st.g(self.name + ".weight"), st.g(self.name + ".bias"), n.gn_ws)
+                          g0, a0, g1, a1, st.g(self.name + ".weight"), st.g(self.name + ".bias"), n.gn_ws, **sums)
 
 
 class _AttnCore:
@@ -448,7 +453,9 @@ class UNet:
             skip = conv(pre + ".skip", x0, x1, Cout, k=1) if Cin != Cout else x0
             a = norm(pre + ".norm1", x0, x1, True)
             h = conv(pre + ".conv1", a, None, Cout, fc=slot)
+            conv1_spec = self.specs[-1]
             b = norm(pre + ".norm2", h, None, True)
+            self.specs[-1].producer = conv1_spec          # norm2's backward also emits conv1's bias / time-embedding sums
             return conv(pre + ".conv2", b, None, Cout, resid=skip)
 
         def att(pre, x):                                  # AttentionBlock (unet6.py:296-333)
