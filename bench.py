@@ -196,8 +196,16 @@ def main():
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         name = "gemm_bf16_kernel" if dt == mdm.BF16 else "gemm_f32_kernel"
         peak = PEAK_BF16_TFLOPS if dt == mdm.BF16 else 157.3
+        # HBM bytes per launch of this kernel family from PMC counters: collected out of band by
+        # scripts/pmc_traffic.sh (rocprofv3 cannot run inside the timed process) and committed under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = round(json.load(fh)["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic,
                     "launches_per_step": n_launch // reps, "flops_per_step": tot_fl / reps,
                     "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "kernel_ms_per_step": round(tot_ms / reps, 3)}
         P = model.num_parameters()

@@ -1,0 +1,29 @@
+#!/bin/bash
+# HBM traffic of the contraction-kernel family per launch, from PMC counters (separate passes, as
+# MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+# half of a wide coalesced read stream, so it is doubled).  Also a kernel-trace --stats summary.
+export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/traffic; rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-sampler"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.json 2> $OUT/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sampler > $OUT/stats.json 2> $OUT/stats.err
+cd $R
+python3 - <<'PY'
+import csv, glob, json
+def per_launch(kind):
+    f = glob.glob(f"gpurun_out/traffic/{kind}/**/*counter_collection.csv", recursive=True)[0]
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if "gemm_" in r["Kernel_Name"] and "f32_kernel" not in r["Kernel_Name"]:
+            tot += float(r["Counter_Value"]); n += 1
+    return tot, n
+f, nf = per_launch("fetch"); w, nw = per_launch("write")
+out = {"kernel_family": "gemm_ring_kernel / gemm_bf16_kernel (bf16 contractions)",
+       "fetch_KiB_raw_per_launch": f / nf, "write_KiB_per_launch": w / nw, "launches_counted": [nf, nw],
+       "hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0,
+       "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; KiB -> bytes x1024",
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-sampler"}
+json.dump(out, open("gpurun_out/traffic/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
