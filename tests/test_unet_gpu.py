@@ -93,3 +93,42 @@ def test_state_dict_roundtrip_and_fresh_init():
     sd = fresh.state_dict()
     assert float(sd["out_conv.2.weight"].abs().max()) < 1e-4 and float(sd["in_conv.weight"].abs().max()) > 1e-2
     assert float(sd["middle.0.norm1.weight"].min()) == 1.0
+
+
+# ------------------------------------------------------------------------------- other BASELINE configs
+CFG4_TINY = dict(in_channels=4, hid_channels=32, out_channels=4, ch_multipliers=[1, 2, 2], num_res_blocks=1,
+                 apply_attn=[True, True, True])          # cfg4: C=4, attention at every level (L = 1024, 256, 64)
+CFG3_TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
+                 apply_attn=[False, False, True, False])  # cfg3: the unet6 preset's topology at 64x64, narrow
+
+
+@pytest.mark.parametrize("name,cfg,hw,n", [("cfg4_attn_everywhere_C4", CFG4_TINY, 32, 2), ("cfg3_64x64", CFG3_TINY, 64, 2)])
+@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
+def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, tol_g):
+    from mdm import ops
+    from mdm import unet as U
+    from oracle.unet_ref import UNetRef, random_params
+    p = random_params(cfg, 11)
+    g = torch.Generator().manual_seed(13)
+    c = cfg["in_channels"]
+    x = torch.rand(n, c, hw, hw, generator=g) * 2 - 1
+    t = torch.tensor([5.0, 321.0][:n])
+    gy = torch.randn(n, c, hw, hw, generator=g)
+    net = U.UNet(cfg, N=n, H=hw, W=hw, dtype=dt, params=p)
+    y = net(x, t).sample
+    net.zero_grad()
+    ops.nchw_to_nhwc(dt, gy.to(net.device), net.y_out.grad, n, c, hw, hw, net.cout_p)
+    net.run_backward()
+    torch.cuda.synchronize()
+    grads = net.store.grad_dict()
+    m = UNetRef(cfg, p)
+    yo = m(x, t).sample
+    (yo * gy).sum().backward()
+    assert _rel(y, yo.detach()) < tol_y
+    want = {k: q.grad for k, q in zip(m.keys, m.plist)}
+    a = torch.cat([grads[k].reshape(-1) for k in want])
+    b = torch.cat([want[k].reshape(-1) for k in want])
+    assert _rel(a, b) < tol_g
+    med = sorted(float(w.norm()) for w in want.values())[len(want) // 2]
+    worst = max((_rel(grads[k], want[k]), k) for k in want if float(want[k].norm()) > 1e-2 * med)
+    assert worst[0] < 2 * tol_g, worst
