@@ -239,6 +239,251 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
     }
 }
 
+// Sum over the lanes of a wave that own the same channel vector (lane ids congruent mod VB, VB a power of two):
+// butterfly over the offsets VB, 2VB, ... 32.  Afterwards lanes 0..VB-1 hold the wave's totals, and only those
+// touch LDS -- 64 lanes adding to one LDS address with ds_add_f32 would serialise completely.
+__device__ __forceinline__ float lanes_sum(float v, int VB) {
+    for (int o = 32; o >= VB; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- register-cached variants (bf16): a lane's share of the slice is at most NP 16-byte vectors per tensor,
+// so it is loaded ONCE (all NP loads in flight together), kept in registers across the statistics and the
+// apply pass, and global memory sees a single read.  Same arithmetic as the streaming kernels above.
+__device__ __forceinline__ float8 unpack8(const uint4& r) {
+    float8 o;
+    o.lo = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    o.hi = make_float4(__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u),
+                       __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u));
+    return o;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
+                                                         float eps, const float* gamma, const float* beta, int silu, bf16_t* y,
+                                                         float* stats) {
+    const int C = C0 + C1, cpg = C / G;
+    const int VB = CBLK / 8, PL = 256 / VB;
+    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
+    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const bool on = t < VB * PL && c < C;
+    __shared__ float gsum[2 * 64], gmean[64], grstd[64];
+    if (t < 2 * ng) gsum[t] = 0.f;
+    __syncthreads();
+    const int64_t base = (int64_t)img * P;
+    uint4 cx[NP];
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = lane + i * PL;
+            cx[i] = p < P ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
+        }
+        float s[8] = {}, q[8] = {}, K[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, (c + e) / cpg, cpg);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (lane + i * PL < P) {
+                float8 x = unpack8(cx[i]);
+                float xv[8] = F8_TO_ARR(x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; s[e] += dlt; q[e] = fmaf(dlt, dlt, q[e]); }
+            }
+        }
+        const bool pow2 = (VB & (VB - 1)) == 0 && VB * PL == 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int gl = (c + e) / cpg - g0;
+            if (pow2) {
+                float a = lanes_sum(s[e], VB), b = lanes_sum(q[e], VB);
+                if ((t & 63) < VB) { atomicAdd(&gsum[2 * gl], a); atomicAdd(&gsum[2 * gl + 1], b); }
+            } else {
+                atomicAdd(&gsum[2 * gl], s[e]);
+                atomicAdd(&gsum[2 * gl + 1], q[e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (t < ng && (g0 + t) < G) {
+        const float inv_cnt = 1.f / ((float)cpg * (float)P);
+        float K = gn_pivot(s0, s1, C0, C1, base, g0 + t, cpg);
+        float md = gsum[2 * t] * inv_cnt;
+        float var = fmaxf(gsum[2 * t + 1] * inv_cnt - md * md, 0.f);
+        float mean = K + md, rstd = rsqrtf(var + eps);
+        gmean[t] = mean; grstd[t] = rstd;
+        stats[((int64_t)img * G + g0 + t) * 2] = mean;
+        stats[((int64_t)img * G + g0 + t) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    if (on) {
+        float m[8], a[8], bt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int gl = (c + e) / cpg - g0;
+            m[e] = gmean[gl]; a[e] = grstd[gl] * gamma[c + e]; bt[e] = beta[c + e];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = lane + i * PL;
+            if (p < P) {
+                float8 x = unpack8(cx[i]);
+                float xv[8] = F8_TO_ARR(x);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = fmaf(xv[e] - m[e], a[e], bt[e]);
+                    if (silu) o[e] = silu_f(o[e]);
+                }
+                float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+                store8(y + (base + p) * C + c, r);
+            }
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
+                                                         const float* gamma, const float* beta, int silu, const bf16_t* dy,
+                                                         const float* stats, bf16_t* d0, int acc0, bf16_t* d1, int acc1,
+                                                         float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
+    const int C = C0 + C1, cpg = C / G;
+    const int VB = CBLK / 8, PL = 256 / VB;
+    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
+    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const bool on = t < VB * PL && c < C;
+    __shared__ float gsum[2 * 64];
+    __shared__ float chan[2 * 64];
+    if (t < 2 * ng) gsum[t] = 0.f;
+    if (t < 2 * CBLK) chan[t] = 0.f;
+    __syncthreads();
+    const int64_t base = (int64_t)img * P;
+    uint4 cx[NP], cd[NP];
+    float ga[8], be[8], mean[8], rstd[8];
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = lane + i * PL;
+            bool ok = p < P;
+            cx[i] = ok ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
+            cd[i] = ok ? *reinterpret_cast<const uint4*>(dy + (base + p) * C + c) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int grp = (c + e) / cpg;
+            ga[e] = gamma[c + e]; be[e] = beta[c + e];
+            mean[e] = stats[((int64_t)img * G + grp) * 2]; rstd[e] = stats[((int64_t)img * G + grp) * 2 + 1];
+        }
+        float a1[8] = {}, a2[8] = {}, dg[8] = {}, db[8] = {};
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (lane + i * PL < P) {
+                float8 x = unpack8(cx[i]), d = unpack8(cd[i]);
+                float xv[8] = F8_TO_ARR(x);
+                float dv[8] = F8_TO_ARR(d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xh = (xv[e] - mean[e]) * rstd[e];
+                    float gz = dv[e];
+                    if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
+                    dg[e] = fmaf(gz, xh, dg[e]); db[e] += gz;
+                    float gg = gz * ga[e];
+                    a1[e] += gg; a2[e] = fmaf(gg, xh, a2[e]);
+                }
+            }
+        }
+        const bool pow2 = (VB & (VB - 1)) == 0 && VB * PL == 256;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int gl = (c + e) / cpg - g0;
+            if (pow2) {
+                float r1 = lanes_sum(a1[e], VB), r2 = lanes_sum(a2[e], VB), r3 = lanes_sum(dg[e], VB), r4 = lanes_sum(db[e], VB);
+                if ((t & 63) < VB) {
+                    atomicAdd(&gsum[2 * gl], r1); atomicAdd(&gsum[2 * gl + 1], r2);
+                    atomicAdd(&chan[v * 8 + e], r3); atomicAdd(&chan[CBLK + v * 8 + e], r4);
+                }
+            } else {
+                atomicAdd(&gsum[2 * gl], a1[e]);
+                atomicAdd(&gsum[2 * gl + 1], a2[e]);
+                atomicAdd(&chan[v * 8 + e], dg[e]);
+                atomicAdd(&chan[CBLK + v * 8 + e], db[e]);
+            }
+        }
+    }
+    __syncthreads();
+    if (t < CBLK && cb + t < C) {
+        atomicAdd(&dgamma[cb + t], chan[t]);
+        atomicAdd(&dbeta[cb + t], chan[CBLK + t]);
+    }
+    float k1[8], k2[8], ag[8];
+    if (on) {
+        const float inv_cnt = 1.f / ((float)cpg * (float)P);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int gl = (c + e) / cpg - g0;
+            k1[e] = rstd[e] * gsum[2 * gl] * inv_cnt;
+            k2[e] = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
+            ag[e] = rstd[e] * ga[e];
+        }
+    }
+    if (sum_img || sum_all) {
+        __syncthreads();
+        if (t < 128) gsum[t] = 0.f;
+        __syncthreads();
+    }
+    if (on) {
+        bf16_t* dst; int acc, cc, CS;
+        if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
+        float sx[8] = {};
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = lane + i * PL;
+            if (p < P) {
+                float8 x = unpack8(cx[i]), d = unpack8(cd[i]);
+                float xv[8] = F8_TO_ARR(x);
+                float dv[8] = F8_TO_ARR(d);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xh = (xv[e] - mean[e]) * rstd[e];
+                    float gz = dv[e];
+                    if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
+                    o[e] = ag[e] * gz - fmaf(xh, k2[e], k1[e]);
+                    sx[e] += o[e];
+                }
+                bf16_t* q = dst + (base + p) * CS + cc;
+                if (acc) {
+                    float8 old = load8(q);
+                    float ov[8] = F8_TO_ARR(old);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += ov[e];
+                }
+                float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+                store8(q, r);
+            }
+        }
+        if (sum_img || sum_all) {
+            const bool pow2 = (VB & (VB - 1)) == 0 && VB * PL == 256;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (pow2) {
+                    float r = lanes_sum(sx[e], VB);
+                    if ((t & 63) < VB) atomicAdd(&gsum[(v * 8 + e)], r);
+                } else atomicAdd(&gsum[(v * 8 + e)], sx[e]);
+            }
+        }
+    }
+    if (sum_img || sum_all) {
+        __syncthreads();
+        if (t < CBLK && cb + t < C) {
+            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = gsum[t];
+            if (sum_all) atomicAdd(&sum_all[cb + t], gsum[t]);
+        }
+    }
+}
+
 // ---- row softmax: one wave per row
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(T* S, int rows, int L) {
@@ -413,6 +658,7 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
 }
 
 // channels per workgroup: whole groups, whole 16-byte vectors, at least 32 channels
+static int g_gn_regs = []() { const char* e = getenv("MDM_GN_REGS"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_gn_minc = []() { const char* e = getenv("MDM_GN_MINC"); return e ? atoi(e) : 32; }();
 static int gn_cblk(int C, int G, int N, int P) {
     int cpg = C / G, l = cpg;
@@ -430,6 +676,15 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     dim3 grid(cdiv(C, cblk), N);
+    const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane
+    if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
+#define GN_FWD_REG(NPV) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                           (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats)
+        if (np <= 1) GN_FWD_REG(1); else if (np <= 2) GN_FWD_REG(2); else if (np <= 4) GN_FWD_REG(4);
+        else if (np <= 8) GN_FWD_REG(8); else GN_FWD_REG(16);
+#undef GN_FWD_REG
+        return launch_status("groupnorm_fwd");
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL((gn_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
                                          (const T*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (T*)y, stats));
     return launch_status("groupnorm_fwd");
@@ -457,6 +712,16 @@ extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     MDM_REQUIRE(!(sum_img || sum_all) || (acc0 == 0 && C1 == 0), "groupnorm_bwd_sums: column sums need a plain (non-accumulating, single-source) dx");
     dim3 grid(cdiv(C, cblk), N);
+    const int np = cdiv(P, 256 / (cblk / 8));
+    if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
+#define GN_BWD_REG(NPV) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                           (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
+                                           (bf16_t*)dst0, acc0, (bf16_t*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all)
+        if (np <= 1) GN_BWD_REG(1); else if (np <= 2) GN_BWD_REG(2); else if (np <= 4) GN_BWD_REG(4);
+        else if (np <= 8) GN_BWD_REG(8); else GN_BWD_REG(16);
+#undef GN_BWD_REG
+        return launch_status("groupnorm_bwd");
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
                                          (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0, acc0,
                                          (T*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all));
