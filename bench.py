@@ -124,9 +124,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
+    # (MDM_FORCE_DEVICE / MDM_DIST_BACKEND exist so the multi-rank path can be rehearsed on a 1-GPU box: two
+    # ranks on cuda:0 over gloo.  The driver's runs use one rank per GPU over "nccl" = RCCL.)
+    if os.environ.get("MDM_FORCE_DEVICE") is not None:
+        local = int(os.environ["MDM_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
-        init_from_env("nccl")
+        init_from_env(os.environ.get("MDM_DIST_BACKEND", "nccl"))
     dev = torch.device("cuda", local)
     dt = mdm.BF16 if opt_.dtype == "bf16" else mdm.F32
     N = opt_.batch

@@ -8,7 +8,12 @@
 
 namespace mdm {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n4, int64_t n, float* out) {
+// Deterministic two-stage reduction: data-parallel replicas must derive the SAME clip coefficient from the
+// same (all-reduced) gradient, bit for bit, or they drift apart -- so no float atomics here.
+constexpr int SQN_BLOCKS = 1024;
+__device__ float g_sqnorm_partials[SQN_BLOCKS];
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n4, int64_t n) {
     float a = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 v = reinterpret_cast<const float4*>(g)[i];
@@ -20,7 +25,16 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n4,
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) g_sqnorm_partials[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(float* out, int nblk) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += g_sqnorm_partials[i];
+    a = wave_sum(a);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) *out += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // hp: lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ema_decay
@@ -85,7 +99,10 @@ using namespace mdm;
 extern "C" int mdm_sqnorm(const float* g, int64_t n, float* out, void* stream) {
     MDM_REQUIRE(g && out && n > 0, "sqnorm: bad arguments");
     MDM_REQUIRE(((uintptr_t)g & 15) == 0, "sqnorm: buffer must be 16-byte aligned");
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(ogrid(n / 4)), dim3(256), 0, (hipStream_t)stream, g, n / 4, n, out);
+    int nb = ogrid(n / 4);
+    if (nb > SQN_BLOCKS) nb = SQN_BLOCKS;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n / 4, n);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, nb);
     return launch_status("sqnorm");
 }
 extern "C" int mdm_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t n,

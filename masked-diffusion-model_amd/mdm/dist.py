@@ -27,7 +27,7 @@ def init_from_env(backend=None):
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-    if backend == "nccl":
+    if backend == "nccl" and os.environ.get("MDM_FORCE_DEVICE") is None:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend)
 

@@ -1,0 +1,79 @@
+"""Data-parallel train step on the GPU with 2 ranks.  Only one GPU is available to this build, so both
+ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); everything else -- bucket
+planning from the backward marks, the backward cut into per-bucket hipGraphs, the all-reduce issued
+between chunks, the 1/world mean folded into the optimizer kernel -- is the code that runs over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "masked-diffusion-model_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+import mdm
+from mdm.dist import GradComm, init_from_env
+from mdm.train_step import TrainStep
+from golden.make_golden import TINY, base_args
+from oracle.unet_ref import random_params
+torch.cuda.set_device(0)
+init_from_env("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=50, shift_type="noise_with_perturbation",
+              rng_mode="device", use_ema=True, seed=100 + rank, use_graph=(sys.argv[2] == "graph"))
+model = mdm.UNet(TINY, N=4, H=16, W=16, dtype=mdm.BF16, params=random_params(TINY), use_graph=a.use_graph)
+opt = mdm.AdamW(model, lr=1e-3)
+ema = mdm.EMA(model)
+S = mdm.Scheduler(a); S.update_ddpm_num_steps(50)
+used = S.get_timesteps_epoch(0, 1)
+comm = GradComm(bucket_bytes=256 << 10)          # small buckets -> several backward chunks on the tiny model
+step = TrainStep(model, S, a, opt, ema, mean_shift=True, comm=comm)
+g = torch.Generator().manual_seed(7 + rank)
+x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+P0 = model.store.P.clone()
+losses = []
+for k in range(4):
+    losses.append(float(step.run_device(x0, used)))
+torch.cuda.synchronize()
+assert len(comm.buckets) >= 3, comm.buckets
+assert comm.buckets[0][1] == model.store.size and comm.buckets[-1][0] == 0
+P = model.store.P.detach().cpu()
+both = [torch.empty_like(P) for _ in range(world)]
+dist.all_gather(both, P)
+# every rank applied the same averaged gradient to the same weights -> identical replicas
+assert torch.equal(both[0], both[1]), float((both[0] - both[1]).abs().max())
+assert float((P - P0.cpu()).abs().max()) > 0 and all(l == l and l < 1e3 for l in losses)
+# the exchanged gradient really is the rank sum: G (still in place after the step) is identical across ranks
+G = model.store.G.detach().cpu()
+gb = [torch.empty_like(G) for _ in range(world)]
+dist.all_gather(gb, G)
+assert torch.equal(gb[0], gb[1])
+assert float(G.abs().max()) > 0
+if rank == 0:
+    print("DPGPU_OK", len(comm.buckets), losses)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_two_ranks_one_gpu_gloo(tmp_path, mode):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert "DPGPU_OK" in outs[0]
