@@ -113,7 +113,7 @@ __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
     int sk = d.splitk < 1 ? 1 : d.splitk;
     int outer = zi / sk, ks = zi - outer * sk;
     z.ks = ks; z.outer = outer;
-    if (d.layout == 2 && d.conv) z.tap = outer; else z.batch = outer;
+    if (d.layout == 2 && d.conv) z.tap = outer; else z.batch = d.conv ? 0 : outer;
     if (sk > 1) {
         int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
         z.kbeg = ks * chunk;
@@ -124,6 +124,11 @@ __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
 
 template <typename T>
 __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z, int m, int n, float4 v) {
+    if (d.splitk > 1 && d.ws && d.layout != 2) {      // raw partial; splitk_epilogue_kernel finishes the job
+        float* p = reinterpret_cast<float*>(d.ws) + (int64_t)z.ks * ((int64_t)d.M * d.N) + (int64_t)m * d.N + n;
+        store4(p, v);
+        return;
+    }
     v.x *= d.alpha; v.y *= d.alpha; v.z *= d.alpha; v.w *= d.alpha;
     if (d.bias) {
         float4 b = *reinterpret_cast<const float4*>(d.bias + n);
@@ -216,6 +221,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
         float4* q = reinterpret_cast<float4*>(D) + i;
         if (acc) { float4 o = *q; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
         *q = a;
+    }
+}
+
+// split-K over the filter taps for the small-M forward / data-gradient convolutions: sums the slabs and
+// applies the whole epilogue (scale, bias, time-embedding row, residual, accumulate, channel split, store)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(mdm_gemm_desc d) {
+    const int n4 = d.N / 4;
+    const int64_t total4 = (int64_t)d.M * n4;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.ks = 0; z.outer = 0;
+    mdm_gemm_desc e = d;
+    e.splitk = 1;                       // epilogue4 must take its plain-store branch
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4* w = reinterpret_cast<const float4*>(d.ws) + i;
+        float4 a = w[0];
+        for (int s = 1; s < d.splitk; ++s) {
+            float4 b = w[(int64_t)s * total4];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        epilogue4<T>(e, z, m, n, a);
     }
 }
 
@@ -639,7 +665,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
         }
     }
     // slab cursor.  TAPMAJOR: segment = (tap, source); c runs over that source's channels.
-    int seg_tap = 0, seg_src = 0, seg_c = 0, tap_ty = 0, tap_tx = 0;
+    // TAPMAJOR split-K: this workgroup owns the taps [z.ks * tps, (z.ks + 1) * tps)
+    const int tps = TAPMAJOR ? (d.KH * d.KW) / (d.splitk < 1 ? 1 : d.splitk) : 0;
+    int seg_tap = TAPMAJOR ? z.ks * tps : 0, seg_src = 0, seg_c = 0;
+    int tap_ty = TAPMAJOR ? seg_tap / d.KW : 0, tap_tx = TAPMAJOR ? seg_tap - (seg_tap / d.KW) * d.KW : 0;
     bool seg_dirty = true;
     int nxt_k = z.kbeg;
     const int nsrc = (TAPMAJOR && d.C1 > 0) ? 2 : 1;
@@ -734,7 +763,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;      // bf16 1.0
 
-    const int nk = TAPMAJOR ? d.KH * d.KW * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
+    const int nk = TAPMAJOR ? tps * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
     // prologue: NSTAGE-1 slabs in flight.  Slabs past the end are issued too (all-zero or harmless
     // re-reads) so that the vmcnt bookkeeping below is the same for every trip count.
 #pragma unroll
@@ -827,9 +856,9 @@ static int validate(const mdm_gemm_desc& d) {
     if (d.dbias) MDM_REQUIRE(d.layout == 2 && d.dtype == MDM_BF16, "gemm: dbias is fused only into the bf16 layout-2 kernel");
     if (d.resid) MDM_REQUIRE(d.ldr % 4 == 0, "gemm: bad resid pitch");
     if (d.splitk > 1) MDM_REQUIRE(d.out_f32 || d.dtype == MDM_F32, "gemm: split-K needs an fp32 destination");
-    if (d.splitk > 1 && d.layout != 2)
-        MDM_REQUIRE(!d.conv && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f,
-                    "gemm: split-K in layouts 0/1 is for plain contractions without an epilogue");
+    if (d.splitk > 1 && d.layout != 2 && !d.conv)
+        MDM_REQUIRE(!d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f,
+                    "gemm: split-K of a plain contraction in layouts 0/1 takes no epilogue");
     return 0;
 }
 
@@ -858,7 +887,7 @@ static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
-    if (d.splitk > 1) return false;
+    if (d.splitk > 1 && !d.conv) return false;
     if (d.conv) return d.Ck % 64 == 0 && d.C0 % 64 == 0 && d.C1 % 64 == 0;
     return d.K % 64 == 0;
 }
@@ -877,6 +906,7 @@ static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); ret
 static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
 static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
+static int g_tap_split = []() { const char* e = getenv("MDM_TAP_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES"); return e ? atoi(e) : 200; }();
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
@@ -903,14 +933,26 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             d.splitk = (int)(want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want));
             if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
         }
-    } else if (d.splitk < 1 || d.conv) {
+    } else if (d.conv) {
+        // small-M forward / data gradient: too few tiles to fill the chip -> split the filter taps over grid z
+        d.splitk = 1;
+        const int taps = d.KH * d.KW;
+        if (g_tap_split && d.ws && d.dtype == MDM_BF16 && ring_eligible(d) && taps >= 9 && taps % 3 == 0 && tiles <= 160) {
+            int sk = tiles <= 48 ? taps : 3;
+            if (taps % sk) sk = 3;
+            if (d.ws_bytes >= (int64_t)sk * d.M * d.N * 4) d.splitk = sk;
+        }
+    } else if (d.splitk < 1) {
         d.splitk = 1;
     }
     // slab mode needs a dense fp32 [tap|batch][M][N] destination and room for every split
+    const bool tap_split = d.conv && d.layout != 2 && d.splitk > 1;
     const bool dense = d.out_f32 && d.N0 == d.N && d.ldd0 == d.N &&
                        (d.layout == 2 && d.conv ? d.dtap == (int64_t)d.M * d.N : (zouter == 1 || d.sD == (int64_t)d.M * d.N));
     const int64_t slab = (int64_t)zouter * d.M * d.N * 4;
-    if (d.splitk > 1 && d.ws && dense && d.ws_bytes >= slab * 2) {
+    if (tap_split) {
+        /* workspace size checked above */
+    } else if (d.splitk > 1 && d.ws && dense && d.ws_bytes >= slab * 2) {
         if (d.ws_bytes < slab * d.splitk) d.splitk = (int)(d.ws_bytes / slab);
     } else {
         d.ws = nullptr;
@@ -935,7 +977,11 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     } else {
         launch_bf16<64, 64>(d, grid, s);
     }
-    if (d.splitk > 1 && d.ws) {
+    if (tap_split) {
+        const int64_t total4 = (int64_t)d.M * d.N / 4;
+        int64_t nb = (total4 + 255) / 256;
+        hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t>), dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s, d);
+    } else if (d.splitk > 1 && d.ws) {
         const int64_t total4 = (int64_t)zouter * d.M * d.N / 4;
         int64_t nb = (total4 + 255) / 256;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s,

@@ -61,14 +61,15 @@ def conv_flops(g: ConvGeom):
     return 2.0 * g.N * g.OH * g.OW * g.Cout * g.Cin * g.taps
 
 
-def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0):
+def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None):
     """out[N,OH,OW,Cout] = conv(concat(src0,src1), w[tap][Cout][Cin]) + bias + rowvec[n] + resid."""
     _lib.gemm(dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
               conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
               pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
               src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, B=w, ldb=g.Cin, wtap=g.Cout * g.Cin,
               D0=out, ldd0=g.Cout, N0=g.Cout, out_f32=out_f32, bias=bias, rowvec=rowvec, rv_ld=rv_ld,
-              rows_per_img=g.OH * g.OW, resid=resid, ldr=g.Cout, _flops=conv_flops(g))
+              rows_per_img=g.OH * g.OW, resid=resid, ldr=g.Cout, _flops=conv_flops(g),
+              ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
 
 
 def conv_dgrad(dt, g: ConvGeom, dy, w, dst0, acc0, dst1=None, acc1=0):
@@ -80,14 +81,15 @@ def conv_dgrad(dt, g: ConvGeom, dy, w, dst0, acc0, dst1=None, acc1=0):
               D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g))
 
 
-def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0):
+def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None):
     """Same gradient as conv_dgrad but with per-tap TRANSPOSED filters wT[tap][Cin][Cout]: both operands
     are k-contiguous (layout 0), the path the forward uses."""
     _lib.gemm(dtype=dt, layout=0, M=g.N * g.VH * g.VW, N=g.Cin, K=g.taps * g.Cout,
               conv=1, OH=g.VH, OW=g.VW, IH=g.OH, IW=g.OW, KH=g.KH, KW=g.KW, stride=g.stride,
               pad_t=g.pad_t, pad_l=g.pad_l, transposed=1, ups=0, C0=g.Cout, C1=0, Ck=g.Cout,
               src0=dy, src1=None, ld0=g.Cout, ld1=0, B=wT, ldb=g.Cout, wtap=g.Cout * g.Cin,
-              D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g))
+              D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g),
+              ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
 
 
 def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None, dbias=None):

@@ -188,7 +188,7 @@ class _Conv:
             rv, ld = n.T_all[:, self.fc_slot:], n.fc_total
         ops.conv_fwd(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
                      st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
-                     resid=self.resid.data if self.resid else None)
+                     resid=self.resid.data if self.resid else None, ws=n.splitk_ws)
 
     def bwd(self):
         n, st, g = self.net, self.net.store, self.g
@@ -221,7 +221,8 @@ class _Conv:
             return
         # bf16: the filters come from the per-tap transposed shadow so both operands are k-contiguous
         if n.dt == BF16:
-            dgrad, wmat = ops.conv_dgrad_t, st.wT(self.name + ".weight")
+            wmat = st.wT(self.name + ".weight")
+            dgrad = lambda *a: ops.conv_dgrad_t(*a, ws=n.splitk_ws)     # small maps split the taps over the grid
         else:
             dgrad, wmat = ops.conv_dgrad, st.w(self.name + ".weight")
         if g.ups:
