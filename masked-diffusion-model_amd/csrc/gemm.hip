@@ -819,6 +819,149 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 }
 
 // ----------------------------------------------------------------------------
+// Specialised ring kernel for the bulk of the convolutions: layout 0 (both operands k-contiguous),
+// stride 1, no folded upsample -- every 3x3 / 1x1 forward and (through the transposed weight
+// shadow) every such data gradient.  There the source pixel is LINEAR in the filter tap:
+//     spix(tap) = base0 + sgn * (ty * IW + tx)
+// so each lane keeps one row pointer per source and a 9-bit validity mask per row, and the slab
+// loop carries almost no address arithmetic: per LDS-DMA piece one 64-bit add of a wave-uniform
+// offset and one select against the zero page.  The loop is unrolled over the ring so stage
+// addresses are immediates.  (PMC on the general kernel: ~100 SALU + ~85 VALU per slab per wave
+// for 16 MFMAs -- instruction issue, not memory, was the limiter.)
+// ----------------------------------------------------------------------------
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_lin_kernel(mdm_gemm_desc d) {
+    constexpr int BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;
+    constexpr int WROWS = NW / 2;
+    constexpr int WM = BM / WROWS, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    const int sk = d.splitk < 1 ? 1 : d.splitk;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.ks = blockIdx.z;
+
+    const int r_sub = lane >> 3, r_lch = (lane & 7) ^ r_sub;
+    const int sgn = d.transposed ? -1 : 1;
+    const int ntaps = d.KH * d.KW;
+
+    // ---- per-row state: pointer to tap (0,0) in each source (may point outside; only used when valid) + validity bits
+    const char* a_row0[GA];
+    const char* a_row1[GA];
+    unsigned a_vmask[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        const int gm = m0 + 8 * (wave * GA + j) + r_sub;
+        RowPix rp = decode_row(d, gm < d.M ? gm : 0);
+        const int by = d.transposed ? rp.oy + d.pad_t : rp.oy - d.pad_t;
+        const int bx = d.transposed ? rp.ox + d.pad_l : rp.ox - d.pad_l;
+        unsigned vm = 0;
+        for (int ty = 0; ty < d.KH; ++ty)
+            for (int tx = 0; tx < d.KW; ++tx) {
+                int iy = by + sgn * ty, ix = bx + sgn * tx;
+                bool ok = gm < d.M && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
+                vm |= (ok ? 1u : 0u) << (ty * d.KW + tx);
+            }
+        a_vmask[j] = vm;
+        const int64_t base0 = ((int64_t)rp.img * d.IH + by) * d.IW + bx;
+        a_row0[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src0) + base0 * d.ld0 + 8 * r_lch);
+        a_row1[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src1) + base0 * d.ld1 + 8 * r_lch);
+    }
+    const char* b_row[GB];
+    bool b_ok[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int gn = n0 + 8 * (wave * GB + j) + r_sub;
+        b_ok[j] = gn < d.N;
+        b_row[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(b_ok[j] ? gn : 0) * d.ldb + 8 * r_lch);
+    }
+
+    // ---- wave-uniform slab cursor of the ISSUE side: (tap, source, channel)
+    const int tps = ntaps / sk;
+    const int tap_beg = z.ks * tps;
+    int i_tap = tap_beg, i_ty = tap_beg / d.KW, i_tx = tap_beg - (tap_beg / d.KW) * d.KW, i_src = 0, i_c = 0;
+    const int nk = tps * (d.Ck / BK);
+    int issued = 0;
+
+    auto issue = [&](char* stage) {
+        const bool live = issued < nk;                                   // over-issued tail slabs re-read slab (0,0,0): harmless
+        const int tap = live ? i_tap : tap_beg, src = live ? i_src : 0, c = live ? i_c : 0;
+        const int ty = live ? i_ty : tap_beg / d.KW, tx = live ? i_tx : tap_beg - (tap_beg / d.KW) * d.KW;
+        const int ld = src ? d.ld1 : d.ld0;
+        const int64_t aoff = ((int64_t)(sgn * (ty * d.IW + tx)) * ld + c) * 2;            // bytes, wave-uniform
+        const int64_t boff = ((int64_t)tap * d.wtap + c + (src ? d.C0 : 0)) * 2;
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+            const char* p = (src ? a_row1[j] : a_row0[j]) + aoff;
+            lds_dma16((((a_vmask[j] >> tap) & 1u) && !(d._p0 & 1)) ? p : zero, stage + (wave * GA + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j)
+            lds_dma16((b_ok[j] && !(d._p0 & 2)) ? b_row[j] + boff : zero, stage + A_BYTES + (wave * GB + j) * 1024);
+        ++issued;
+        i_c += BK;
+        if (i_c >= (i_src ? d.C1 : d.C0)) {
+            i_c = 0;
+            if (++i_src == (d.C1 > 0 ? 2 : 1)) {
+                i_src = 0; ++i_tap;
+                if (++i_tx == d.KW) { i_tx = 0; ++i_ty; }
+            }
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s2 = 0; s2 < NSTAGE - 1; ++s2) issue(ring + s2 * STAGE_BYTES);
+
+    for (int it0 = 0; it0 < nk; it0 += NSTAGE) {
+#pragma unroll
+        for (int s2 = 0; s2 < NSTAGE; ++s2) {             // stage index == s2: LDS addresses are immediates
+            if (it0 + s2 < nk) {
+                wait_vmcnt<(NSTAGE - 2) * G>();
+                __builtin_amdgcn_s_barrier();
+                issue(ring + ((s2 + NSTAGE - 1) % NSTAGE) * STAGE_BYTES);
+                const char* As = ring + s2 * STAGE_BYTES;
+                const char* Bs = As + A_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < BK / 32; ++ks) {
+                    bf16x8 af[MI], bfr[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = ring_frag_rows(As, wr * WM + i * 16, ks, lane);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) bfr[j] = ring_frag_rows(Bs, wc * WN + j * 16, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = m0 + wr * WM + i * 16 + (lane & 15);
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // host launch
 // ----------------------------------------------------------------------------
 static int validate(const mdm_gemm_desc& d) {
@@ -884,6 +1027,19 @@ static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     }
 }
 
+template <int BM, int BN, int NSTAGE, int NW>
+static int launch_lin(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lin_kernel<BM, BN, NSTAGE, NW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv_lin_kernel<BM, BN, NSTAGE, NW>), grid, dim3(64 * NW), bytes, s, d);
+    return 0;
+}
+
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
@@ -906,6 +1062,9 @@ static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); ret
 static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
 static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
+static int g_lin_tile = []() { const char* e = getenv("MDM_LIN_TILE"); return e ? atoi(e) : 0; }();
+static int g_dbg_flags = []() { const char* e = getenv("MDM_DBG_FLAGS"); return e ? atoi(e) : 0; }();
+static int g_use_lin = []() { const char* e = getenv("MDM_NO_LIN"); return (e && e[0] == '1') ? 0 : 1; }();
 static int g_tap_split = []() { const char* e = getenv("MDM_TAP_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES"); return e ? atoi(e) : 200; }();
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
@@ -916,6 +1075,7 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     MDM_REQUIRE(dh != nullptr, "gemm: null descriptor");
     mdm_gemm_desc d = *dh;
     if (d.N0 == 0) d.N0 = d.N;
+    d._p0 = g_dbg_flags;        // timing experiments only (bit 0: A operand from the zero page, bit 1: B operand)
     if (int rc = validate(d)) return rc;
     int zouter = d.batch;
     if (d.layout == 2 && d.conv) zouter = d.KH * d.KW;
@@ -966,6 +1126,21 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
+    } else if (g_use_ring && g_use_lin && ring_eligible(d) && d.layout == 0 && d.conv && d.stride == 1 && d.ups == 0 &&
+               d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
+        // tile choice (measured per shape): the largest tile that still gives the chip ~one workgroup per CU --
+        // 128x128 for the 32x32 maps, 64x128 for the 16x16 maps (+20 % over 64x64), 64x64 below that
+        int rc;
+        const int64_t t_mid = (int64_t)cdiv(d.M, 64) * cdiv(d.N, 128) * grid.z;
+        if (big) {
+            rc = launch_lin<128, 128, 3, 8>(d, grid, s);
+        } else if (!g_force_small && d.N >= 128 && t_mid >= g_big_min_tiles && g_lin_tile != 9) {
+            dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
+            rc = launch_lin<64, 128, 3, 8>(d, g2, s);
+        } else {
+            rc = launch_lin<64, 64, 4, 8>(d, grid, s);
+        }
+        if (rc) return rc;
     } else if (g_use_ring && ring_eligible(d)) {
         int rc = big ? (g_big_waves == 16 ? launch_ring<128, 128, 3, 16>(d, grid, s) : g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
                                          : launch_ring<128, 128, 3>(d, grid, s))
