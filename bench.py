@@ -13,8 +13,8 @@ optimisation step (degrade -> shift -> U-Net fwd -> loss -> U-Net bwd -> [all-re
 on a batch that is already resident in HBM.  One JSON line on stdout (rank 0).
 
 Extra objects in that line:
-  roofline     the contraction kernel family (`gemm_bf16_kernel`: every conv fwd/dgrad/wgrad, 1x1 conv
-               and attention product of the step): algorithmic FLOPs of those launches / their HIP-event
+  roofline     the contraction kernel family (every `mdm_gemm` launch of the step -- `conv_lin_kernel` /
+               `gemm_ring_kernel`: conv fwd/dgrad/wgrad, 1x1 convs, attention products): algorithmic FLOPs of those launches / their HIP-event
                time, against the dense bf16 MFMA peak;
   step_hbm     north_star's whole-step figure: algorithmic bytes (SURVEY 8(d) counting rule) /
                (step time x 8 TB/s);
@@ -198,7 +198,8 @@ def main():
         torch.cuda.synchronize()
         log("event-timed replay done")
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        name = "gemm_bf16_kernel" if dt == mdm.BF16 else "gemm_f32_kernel"
+        name = ("mdm_gemm bf16 family: conv_lin_kernel / gemm_ring_kernel (+ splitk reduce/epilogue)" if dt == mdm.BF16
+                else "gemm_f32_kernel")
         peak = PEAK_BF16_TFLOPS if dt == mdm.BF16 else 157.3
         # HBM bytes per launch of this kernel family from PMC counters: collected out of band by
         # scripts/pmc_traffic.sh (rocprofv3 cannot run inside the timed process) and committed under profiles/

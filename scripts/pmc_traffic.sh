@@ -12,14 +12,20 @@ cd $R
 python3 - <<'PY'
 import csv, glob, json
 def per_launch(kind):
-    f = glob.glob(f"gpurun_out/traffic/{kind}/**/*counter_collection.csv", recursive=True)[0]
+    import os
+    f = max(glob.glob(f"gpurun_out/traffic/{kind}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    # every kernel an mdm_gemm call launches in the bf16 step (main contraction + its split-K reduce / epilogue),
+    # divided by the number of main contraction launches = number of mdm_gemm calls
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if "gemm_" in r["Kernel_Name"] and "f32_kernel" not in r["Kernel_Name"]:
-            tot += float(r["Counter_Value"]); n += 1
+        k = r["Kernel_Name"]
+        main = ("gemm_ring_kernel" in k) or ("gemm_bf16_kernel" in k) or ("conv_lin_kernel" in k)
+        if main or "splitk_" in k:
+            tot += float(r["Counter_Value"])
+            n += 1 if main else 0
     return tot, n
 f, nf = per_launch("fetch"); w, nw = per_launch("write")
-out = {"kernel_family": "gemm_ring_kernel / gemm_bf16_kernel (bf16 contractions)",
+out = {"kernel_family": "conv_lin_kernel / gemm_ring_kernel / gemm_bf16_kernel + their splitk_* kernels (all bf16 mdm_gemm calls)",
        "fetch_KiB_raw_per_launch": f / nf, "write_KiB_per_launch": w / nw, "launches_counted": [nf, nw],
        "hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0,
        "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; KiB -> bytes x1024",
