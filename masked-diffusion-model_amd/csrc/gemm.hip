@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(mdm_gemm_desc d) {
 // Eligible: every 64-wide k-slab lies in one filter tap (Ck % 64 == 0), or no gather and
 // K % 64 == 0, or layout 2 (k = rows).  Everything else runs on the kernel above.
 // ----------------------------------------------------------------------------
-__device__ uint4 g_zero_page[64];          // 1 KiB of zeros, the source of every padded 16-byte chunk
+__device__ uint4 g_zero_page[1024];        // 16 KiB of zeros, the source of every padded 16-byte chunk (conv_lin2 walks inside it)
 
 __device__ __forceinline__ int swz_rows(int row) { return row & 7; }                       // [rows][64] image, 8 chunks/row
 template <int CPR> __device__ __forceinline__ int swz_cols(int row) {                      // [64][cols] image
@@ -961,6 +961,317 @@ __global__ __launch_bounds__(64 * NW) void conv_lin_kernel(mdm_gemm_desc d) {
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// conv_lin2: the same contraction as conv_lin_kernel with the ISSUE side reduced to its minimum.
+// The ISA of conv_lin_kernel spends ~120 scalar + ~70 vector instructions per k-slab per wave around
+// 16 MFMAs (tap decode, selects against the zero page, M0 through readfirstlane); with both waves of a
+// SIMD in lockstep behind the slab barrier that instruction stream, not MFMA/LDS/L2, sets the slab time.
+// Here every LDS-DMA piece owns ONE 64-bit pointer that is re-aimed only when the (tap, source) segment
+// changes and otherwise just advances by 128 bytes per slab; invalid taps / tails point into a 16-KiB
+// zero page and walk inside it, so the slab loop has no select at all.  The wave index is made provably
+// uniform (readfirstlane once) so LDS destinations live in SGPRs.  Waves are laid out WR x WC x WK:
+// WK = 2 splits the two 32-wide k-steps of a slab between wave pairs (64x64 wave tiles: 1.5x fewer LDS
+// fragment reads than 32x64), the pair's accumulators meet in LDS once at the end.
+// ----------------------------------------------------------------------------
+#ifdef MDM_STAMP
+// debug build only (make EXTRA=-DMDM_STAMP): cycles per phase of the slab loop, summed over waves
+__device__ unsigned long long g_stamp_buf[4096 * 32];     // one 32-entry record per wave, plain stores
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MDM_T(...) __VA_ARGS__
+#else
+#define MDM_T(...)
+#endif
+
+template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false>
+__global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_desc d) {
+    constexpr int BK = 64, NW = WR * WC * WK;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;
+    constexpr int WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, KSN = 2 / WK;
+    static_assert(GA >= 1 && GB >= 1 && MI >= 1 && NI >= 1 && KSN >= 1, "tile too small for this wave layout");
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
+    MDM_T(const unsigned long long t_entry = stamp_now();)
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+    const int sk = d.splitk < 1 ? 1 : d.splitk;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.ks = blockIdx.z;
+
+    const int r_sub = lane >> 3, r_lch = (lane & 7) ^ r_sub;
+    const int sgn = d.transposed ? -1 : 1;
+    const int ntaps = d.KH * d.KW;
+
+    const char* a_row0[GA];
+    const char* a_row1[GA];
+    unsigned a_vmask[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        const int gm = m0 + 8 * (wave * GA + j) + r_sub;
+        RowPix rp = decode_row(d, gm < d.M ? gm : 0);
+        const int by = d.transposed ? rp.oy + d.pad_t : rp.oy - d.pad_t;
+        const int bx = d.transposed ? rp.ox + d.pad_l : rp.ox - d.pad_l;
+        unsigned vm = 0;
+        for (int ty = 0; ty < d.KH; ++ty)
+            for (int tx = 0; tx < d.KW; ++tx) {
+                int iy = by + sgn * ty, ix = bx + sgn * tx;
+                bool ok = gm < d.M && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
+                vm |= (ok ? 1u : 0u) << (ty * d.KW + tx);
+            }
+        if (d._p0 & 1) vm = 0;
+        a_vmask[j] = vm;
+        const int64_t base0 = ((int64_t)rp.img * d.IH + by) * d.IW + bx;
+        a_row0[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src0) + base0 * d.ld0 + 8 * r_lch);
+        a_row1[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src1) + base0 * d.ld1 + 8 * r_lch);
+    }
+    const char* b_row[GB];
+    bool b_ok[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int gn = n0 + 8 * (wave * GB + j) + r_sub;
+        b_ok[j] = gn < d.N && !(d._p0 & 2);
+        b_row[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(gn < d.N ? gn : 0) * d.ldb + 8 * r_lch);
+    }
+
+    // ---- issue cursor (all wave-uniform): filter tap, source, channel; one live pointer per piece
+    const int tps = ntaps / sk;
+    const int tap_beg = z.ks * tps;
+    int i_tap = tap_beg, i_ty = tap_beg / d.KW, i_tx = tap_beg - (tap_beg / d.KW) * d.KW, i_src = 0, i_c = 0;
+    const int nk = tps * (d.Ck / BK);
+    int issued = 0;
+    int i_stage = 0;                    // byte offset of the stage the next issue fills
+    const char* pa[GA];
+    const char* pb[GB];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) pa[j] = zlane;
+#pragma unroll
+    for (int j = 0; j < GB; ++j) pb[j] = zlane;
+
+    auto issue_prepare = [&]() {
+        if (i_c == 0) {                                          // new (tap, source) segment: re-aim
+            if (issued < nk) {
+                const int ld = i_src ? d.ld1 : d.ld0;
+                const int64_t aoff = (int64_t)(sgn * (i_ty * d.IW + i_tx)) * ld * 2;
+                const int64_t boff = ((int64_t)i_tap * d.wtap + (i_src ? d.C0 : 0)) * 2;
+#pragma unroll
+                for (int j = 0; j < GA; ++j)
+                    pa[j] = ((a_vmask[j] >> i_tap) & 1u) ? (i_src ? a_row1[j] : a_row0[j]) + aoff : zlane;
+#pragma unroll
+                for (int j = 0; j < GB; ++j) pb[j] = b_ok[j] ? b_row[j] + boff : zlane;
+            } else {                                             // over-issued tail slabs: zeros
+#pragma unroll
+                for (int j = 0; j < GA; ++j) pa[j] = zlane;
+#pragma unroll
+                for (int j = 0; j < GB; ++j) pb[j] = zlane;
+            }
+        }
+    };
+    auto issue_piece = [&](int g) {                              // g is a compile-time constant after unrolling
+        char* stage = ring + i_stage;
+#pragma unroll
+        for (int j = 0; j < GA; ++j)
+            if (g == j) { lds_dma16(pa[j], stage + (wave * GA + j) * 1024); pa[j] += 128; }
+#pragma unroll
+        for (int j = 0; j < GB; ++j)
+            if (g == GA + j) { lds_dma16(pb[j], stage + A_BYTES + (wave * GB + j) * 1024); pb[j] += 128; }
+    };
+    auto issue_finish = [&]() {
+        i_stage += STAGE_BYTES;
+        if (i_stage == NSTAGE * STAGE_BYTES) i_stage = 0;
+        if (++issued <= nk) {
+            i_c += BK;
+            if (i_c >= (i_src ? d.C1 : d.C0)) {
+                i_c = 0;
+                if (++i_src == (d.C1 > 0 ? 2 : 1)) {
+                    i_src = 0; ++i_tap;
+                    if (++i_tx == d.KW) { i_tx = 0; ++i_ty; }
+                }
+            }
+            if (issued == nk) i_c = 0;                           // next call re-aims at the zero page
+        }
+    };
+    auto issue = [&]() {
+        issue_prepare();
+#pragma unroll
+        for (int g = 0; g < G; ++g) issue_piece(g);
+        issue_finish();
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets of this lane inside a stage (the swizzle term depends on lane and k-step only)
+    int a_off[KSN], b_off[KSN];
+#pragma unroll
+    for (int q = 0; q < KSN; ++q) {
+        const int ks = wk + q * WK;
+        const int ch = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+        a_off[q] = (wr * WM + (lane & 15)) * 128 + ch;
+        b_off[q] = A_BYTES + (wc * WN + (lane & 15)) * 128 + ch;
+    }
+
+    int c_stage = 0;
+    MDM_T(unsigned long long tw = 0, ti = 0, tc = 0, tb = 0; unsigned long long tis[12] = {}, tbs[12] = {}; unsigned long long tstart = 0;)
+    if constexpr (PIPE) {
+        // Software-pipelined slab loop.  The fragments of k-step 1 are read while k-step 0 multiplies, the
+        // barrier sits in the MIDDLE of a slab (after it every wave has read slab `it` completely, so its
+        // stage takes slab it+NSTAGE at once), the fragments of the next slab's k-step 0 are read while
+        // k-step 1 multiplies, and the LDS-DMA pieces of the refill are dealt out between those MFMAs
+        // (all waves issuing their pieces in one burst right behind the barrier queued ~500 cycles on the
+        // CU's address unit per slab with the matrix pipe idle).
+        static_assert(!PIPE || KSN == 2, "pipelined loop: both k-steps in one wave");
+        // STAG: waves NW/2.. run half a slab BEHIND waves 0..NW/2-1 (the barrier sits before their k-step 0
+        // instead of after it), so on every SIMD one wave multiplies (phase A) while its partner sits in the
+        // DMA-issue-heavy phase B.  The late waves still read slab k while the early ones already refill, so
+        // the refill goes one stage further back: slab k+3 replaces slab k-1 and the ring has 4 stages.
+        static_assert(!STAG || NSTAGE == 4, "staggered loop: refill distance 3 needs 4 stages");
+        constexpr int AHEAD = STAG ? 3 : NSTAGE;                 // slabs issued before the loop
+        const bool late = STAG && wave >= NW / 2;
+#pragma unroll
+        for (int s2 = 0; s2 < AHEAD; ++s2) issue();
+        wait_vmcnt<(AHEAD - 1) * G>();
+        __builtin_amdgcn_s_barrier();
+        bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(ring + a_off[0] + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf0[j] = *reinterpret_cast<const bf16x8*>(ring + b_off[0] + j * 2048);
+        MDM_T(tstart = stamp_now();)
+        auto phase_a = [&]() {
+            const char* st = ring + c_stage;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af1[i] = *reinterpret_cast<const bf16x8*>(st + a_off[1] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf1[j] = *reinterpret_cast<const bf16x8*>(st + b_off[1] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);
+        };
+        for (int it = 0; it < nk; ++it) {
+            MDM_T(const unsigned long long t0 = stamp_now();)
+            if (!late) phase_a();
+            __builtin_amdgcn_sched_barrier(0);
+            MDM_T(const unsigned long long t0b = stamp_now();)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read this wave has issued has returned
+            wait_vmcnt<(AHEAD - 2) * G>();                       // slab it+1 of this wave has landed
+            MDM_T(const unsigned long long t1 = stamp_now();)
+            __builtin_amdgcn_s_barrier();
+            MDM_T(const unsigned long long t2 = stamp_now();)
+            __builtin_amdgcn_sched_barrier(0);
+            if (late) phase_a();
+            c_stage += STAGE_BYTES;
+            if (c_stage == NSTAGE * STAGE_BYTES) c_stage = 0;
+            const char* sn = ring + c_stage;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const bf16x8*>(sn + a_off[0] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf0[j] = *reinterpret_cast<const bf16x8*>(sn + b_off[0] + j * 2048);
+            issue_prepare();
+            constexpr int NM = MI * NI, EVERY = NM / G > 0 ? NM / G : 1;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
+                    const int m = i * NI + j;
+                    if (m % EVERY == EVERY - 1 && m / EVERY < G) issue_piece(m / EVERY);
+                }
+#pragma unroll
+            for (int g = NM / EVERY; g < G; ++g) issue_piece(g);
+            issue_finish();
+            MDM_T(const unsigned long long t3 = stamp_now(); tw += t0b - t0; tb += t2 - t1; ti += t1 - t0b; tc += t3 - t2;)
+        }
+    } else {
+#pragma unroll
+    for (int s2 = 0; s2 < NSTAGE - 1; ++s2) issue();
+    MDM_T(tstart = stamp_now();)
+    for (int it = 0; it < nk; ++it) {
+        MDM_T(const unsigned long long t0 = stamp_now();)
+        wait_vmcnt<(NSTAGE - 2) * G>();
+        MDM_T(const unsigned long long t0b = stamp_now();)
+        __builtin_amdgcn_s_barrier();
+        MDM_T(const unsigned long long t1 = stamp_now();)
+        issue();
+        MDM_T(const unsigned long long t2 = stamp_now();)
+        const char* st = ring + c_stage;
+#pragma unroll
+        for (int q = 0; q < KSN; ++q) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off[q] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off[q] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        c_stage += STAGE_BYTES;
+        if (c_stage == NSTAGE * STAGE_BYTES) c_stage = 0;
+        MDM_T(const unsigned long long t3 = stamp_now(); tw += t0b - t0; tb += t1 - t0b; ti += t2 - t1; tc += t3 - t2;
+              _Pragma("unroll") for (int q = 0; q < 12; ++q) if (it == q) { tis[q] = t2 - t1; tbs[q] = t1 - t0b; })
+    }
+    }
+    wait_vmcnt<0>();
+    MDM_T(const unsigned long long t_loop_end = stamp_now();)
+    if (WK == 2) {                      // the k-halves of a wave pair meet in LDS (the ring is free now)
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(ring) + (wrc * MI * NI) * 64 + lane;
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) red[(i * NI + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (wk == 1) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                f32x4 o = red[(i * NI + j) * 64];
+                acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = m0 + wr * WM + i * 16 + (lane & 15);
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+#ifdef MDM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const unsigned widx = (blockIdx.z * gridDim.x + blockIdx.x) * NW + wave;
+        if (widx < 4096) {
+            unsigned long long* r = g_stamp_buf + widx * 32;
+            r[0] = tw; r[1] = tb; r[2] = ti; r[3] = tc; r[4] = nk; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
+            r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
+        }
+    }
+#endif
+}
+
 // ----------------------------------------------------------------------------
 // host launch
 // ----------------------------------------------------------------------------
@@ -1040,6 +1351,20 @@ static int launch_lin(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     return 0;
 }
 
+template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false>
+static int launch_lin2(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
+    static_assert(WK == 1 || (BM * BN * 4) / WK <= bytes, "reduction scratch must fit the ring");
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, WK, PIPE, STAG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, WK, PIPE, STAG>), grid, dim3(64 * WR * WC * WK), bytes, s, d);
+    return 0;
+}
+
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
@@ -1070,6 +1395,7 @@ static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES");
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
+static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
 
 int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     MDM_REQUIRE(dh != nullptr, "gemm: null descriptor");
@@ -1132,13 +1458,23 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         // 128x128 for the 32x32 maps, 64x128 for the 16x16 maps (+20 % over 64x64), 64x64 below that
         int rc;
         const int64_t t_mid = (int64_t)cdiv(d.M, 64) * cdiv(d.N, 128) * grid.z;
+        const bool lin2 = g_lin2 && d.C0 <= 4096 && d.C1 <= 4096;     // a segment walks <= 8 KiB inside the zero page
         if (big) {
-            rc = launch_lin<128, 128, 3, 8>(d, grid, s);
+            rc = !lin2 ? launch_lin<128, 128, 3, 8>(d, grid, s)
+                 : g_lin2 == 2 ? launch_lin2<128, 128, 3, 2, 2, 2>(d, grid, s)
+                 : g_lin2 == 4 ? launch_lin2<128, 128, 4, 4, 2, 1, true, true>(d, grid, s)
+                 : g_lin2 == 3 ? launch_lin2<128, 128, 3, 4, 2, 1, true>(d, grid, s) : launch_lin2<128, 128, 3, 4, 2, 1>(d, grid, s);
         } else if (!g_force_small && d.N >= 128 && t_mid >= g_big_min_tiles && g_lin_tile != 9) {
             dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
-            rc = launch_lin<64, 128, 3, 8>(d, g2, s);
+            rc = !lin2 ? launch_lin<64, 128, 3, 8>(d, g2, s)
+                 : g_lin2 == 2 ? launch_lin2<64, 128, 3, 1, 4, 2>(d, g2, s)
+                 : g_lin2 == 4 ? launch_lin2<64, 128, 4, 2, 4, 1, true, true>(d, g2, s)
+                 : g_lin2 == 3 ? launch_lin2<64, 128, 3, 2, 4, 1, true>(d, g2, s) : launch_lin2<64, 128, 3, 2, 4, 1>(d, g2, s);
         } else {
-            rc = launch_lin<64, 64, 4, 8>(d, grid, s);
+            rc = !lin2 ? launch_lin<64, 64, 4, 8>(d, grid, s)
+                 : g_lin2 == 2 ? launch_lin2<64, 64, 4, 2, 2, 2>(d, grid, s)
+                 : g_lin2 == 4 ? launch_lin2<64, 64, 4, 4, 2, 1, true, true>(d, grid, s)
+                 : g_lin2 == 3 ? launch_lin2<64, 64, 4, 4, 2, 1, true>(d, grid, s) : launch_lin2<64, 64, 4, 4, 2, 1>(d, grid, s);
         }
         if (rc) return rc;
     } else if (g_use_ring && ring_eligible(d)) {
@@ -1166,6 +1502,17 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
 }
 
 }  // namespace mdm
+
+#ifdef MDM_STAMP
+extern "C" int mdm_debug_stamps(unsigned long long* out, int reset) {      // out: 4096 * 32 entries
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdm::g_stamp_buf), 4096 * 32 * 8) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mdm::g_stamp_buf)) != hipSuccess || hipMemset(p, 0, 4096 * 32 * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
     return mdm::gemm_launch(desc_host, mdm::pick_stream(stream));

@@ -53,8 +53,12 @@ for (c0, c1, co, H, k, s, ups, cnt) in shapes:
     gx1 = torch.empty(N, g.VH, g.VW, c1, device=dev, dtype=bf) if c1 else None
     gw = torch.zeros(k * k, co, c0 + c1, device=dev)
     fl = ops.conv_flops(g)
-    t_f = timeit(lambda: ops.conv_fwd(1, g, x0, x1, w, b, y)) if "fwd" in PASSES else 1e9
-    t_d = timeit(lambda: ops.conv_dgrad(1, g, dy, w, gx0, 0, gx1, 0)) if "dgrad" in PASSES else 1e9
+    t_f = timeit(lambda: ops.conv_fwd(1, g, x0, x1, w, b, y, ws=WS)) if "fwd" in PASSES else 1e9
+    wT = w.transpose(1, 2).contiguous()
+    if ups:        # folded upsample: the general gather path (as in the model)
+        t_d = timeit(lambda: ops.conv_dgrad_t(1, g, dy, wT, torch.empty(N, g.VH, g.VW, c0, device=dev, dtype=bf), 0, ws=WS)) if "dgrad" in PASSES else 1e9
+    else:
+        t_d = timeit(lambda: ops.conv_dgrad_t(1, g, dy, wT, gx0, 0, gx1, 0, ws=WS)) if "dgrad" in PASSES else 1e9
     t_w = timeit(lambda: ops.conv_wgrad(1, g, dy, x0, x1, gw, ws=WS)) if "wgrad" in PASSES else 1e9
     name = f"{c0}+{c1}->{co} @{H} k{k} s{s}{' up' if ups else ''} x{cnt}"
     print(f"{name:38s} {fl/1e9:6.2f} | {t_f:8.1f} {fl/t_f/1e6:6.1f} | {t_d:8.1f} {fl/t_d/1e6:6.1f} | {t_w:8.1f} {fl/t_w/1e6:6.1f}")
