@@ -242,9 +242,31 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
 // Sum over the lanes of a wave that own the same channel vector (lane ids congruent mod VB, VB a power of two):
 // butterfly over the offsets VB, 2VB, ... 32.  Afterwards lanes 0..VB-1 hold the wave's totals, and only those
 // touch LDS -- 64 lanes adding to one LDS address with ds_add_f32 would serialise completely.
-__device__ __forceinline__ float lanes_sum(float v, int VB) {
-    for (int o = 32; o >= VB; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- workgroup column sums through LDS.  Every thread holds K partial values; thread t belongs to column
+// v = t % VB (its 8-channel vector) and the sums run over the 256/VB pixel lanes of each column.
+// (The first version reduced with __shfl_xor: 4 ds_bpermute round trips per value, 128 per thread in the
+// backward -- 20k cycles of a 36k-cycle kernel.)  scratch: K * CS_PITCH floats; out[k * VB + v].
+constexpr int CS_PITCH = 260;
+template <int K>
+__device__ __forceinline__ void block_colsum(const float (&val)[K], float* scratch, float* out, int t, int VB, int PL) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) scratch[k * CS_PITCH + t] = val[k];
+    __syncthreads();
+    const int cols = K * VB;                       // <= 256
+    int tpc = 1;                                   // threads per column (power of two)
+    while (tpc * 2 * cols <= 256) tpc *= 2;
+    const int col = t / tpc, part = t - col * tpc;
+    float sum = 0.f;
+    if (col < cols) {
+        const int k = col / VB, v = col - k * VB;
+        const int per = (PL + tpc - 1) / tpc;
+        const int l0 = part * per, l1 = min(PL, l0 + per);
+        const float* src = scratch + k * CS_PITCH + v;
+        for (int l = l0; l < l1; ++l) sum += src[l * VB];
+    }
+    for (int o = 1; o < tpc; o <<= 1) sum += __shfl_xor(sum, o, 64);     // <= 3 steps on ONE value
+    if (col < cols && part == 0) out[col] = sum;
+    __syncthreads();
 }
 
 // ---- register-cached variants (bf16): a lane's share of the slice is at most NP 16-byte vectors per tensor,
@@ -259,6 +281,20 @@ __device__ __forceinline__ float8 unpack8(const uint4& r) {
     return o;
 }
 
+#ifdef MDM_STAMP
+__device__ unsigned long long g_nstamp_buf[4096 * 16];
+__device__ __forceinline__ unsigned long long nstamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MDM_T(...) __VA_ARGS__
+#else
+#define MDM_T(...)
+#endif
+
 template <int NP>
 __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          float eps, const float* gamma, const float* beta, int silu, bf16_t* y,
@@ -269,18 +305,22 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
+    __shared__ float scratch[16 * CS_PITCH];
+    __shared__ float csum[16 * 8];
     __shared__ float gsum[2 * 64], gmean[64], grstd[64];
     if (t < 2 * ng) gsum[t] = 0.f;
-    __syncthreads();
     const int64_t base = (int64_t)img * P;
     uint4 cx[NP];
+    float part[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part[k] = 0.f;
     if (on) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             int p = lane + i * PL;
             cx[i] = p < P ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
         }
-        float s[8] = {}, q[8] = {}, K[8];
+        float K[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, (c + e) / cpg, cpg);
 #pragma unroll
@@ -289,21 +329,15 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
                 float8 x = unpack8(cx[i]);
                 float xv[8] = F8_TO_ARR(x);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; s[e] += dlt; q[e] = fmaf(dlt, dlt, q[e]); }
+                for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; part[e] += dlt; part[8 + e] = fmaf(dlt, dlt, part[8 + e]); }
             }
         }
-        const bool pow2 = (VB & (VB - 1)) == 0 && VB * PL == 256;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
-            if (pow2) {
-                float a = lanes_sum(s[e], VB), b = lanes_sum(q[e], VB);
-                if ((t & 63) < VB) { atomicAdd(&gsum[2 * gl], a); atomicAdd(&gsum[2 * gl + 1], b); }
-            } else {
-                atomicAdd(&gsum[2 * gl], s[e]);
-                atomicAdd(&gsum[2 * gl + 1], q[e]);
-            }
-        }
+    }
+    block_colsum<16>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
+    if (t < CBLK && cb + t < C) {
+        const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
+        atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
+        atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
     }
     __syncthreads();
     if (t < ng && (g0 + t) < G) {
@@ -319,10 +353,14 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     __syncthreads();
     if (on) {
         float m[8], a[8], bt[8];
+        const float4 g_lo = *reinterpret_cast<const float4*>(gamma + c), g_hi = *reinterpret_cast<const float4*>(gamma + c + 4);
+        const float4 b_lo = *reinterpret_cast<const float4*>(beta + c), b_hi = *reinterpret_cast<const float4*>(beta + c + 4);
+        const float gv[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
+        const float bv[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int gl = (c + e) / cpg - g0;
-            m[e] = gmean[gl]; a[e] = grstd[gl] * gamma[c + e]; bt[e] = beta[c + e];
+            m[e] = gmean[gl]; a[e] = grstd[gl] * gv[e]; bt[e] = bv[e];
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -354,14 +392,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
+    __shared__ float scratch[32 * CS_PITCH];
+    __shared__ float csum[32 * 8];
     __shared__ float gsum[2 * 64];
-    __shared__ float chan[2 * 64];
+    MDM_T(const unsigned long long ts0 = nstamp_now();)
     if (t < 2 * ng) gsum[t] = 0.f;
-    if (t < 2 * CBLK) chan[t] = 0.f;
-    __syncthreads();
     const int64_t base = (int64_t)img * P;
     uint4 cx[NP], cd[NP];
     float ga[8], be[8], mean[8], rstd[8];
+    float part[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) part[k] = 0.f;
+    MDM_T(unsigned long long ts1 = 0;)
     if (on) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -370,13 +412,23 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
             cx[i] = ok ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
             cd[i] = ok ? *reinterpret_cast<const uint4*>(dy + (base + p) * C + c) : make_uint4(0, 0, 0, 0);
         }
+        {
+            const float4 g_lo = *reinterpret_cast<const float4*>(gamma + c), g_hi = *reinterpret_cast<const float4*>(gamma + c + 4);
+            const float4 b_lo = *reinterpret_cast<const float4*>(beta + c), b_hi = *reinterpret_cast<const float4*>(beta + c + 4);
+            ga[0] = g_lo.x; ga[1] = g_lo.y; ga[2] = g_lo.z; ga[3] = g_lo.w; ga[4] = g_hi.x; ga[5] = g_hi.y; ga[6] = g_hi.z; ga[7] = g_hi.w;
+            be[0] = b_lo.x; be[1] = b_lo.y; be[2] = b_lo.z; be[3] = b_lo.w; be[4] = b_hi.x; be[5] = b_hi.y; be[6] = b_hi.z; be[7] = b_hi.w;
+            // 8 consecutive channels touch at most 8/cpg + 1 groups; load each group's pair once
+            const int gA = c / cpg;
+            float2 st_prev = *reinterpret_cast<const float2*>(stats + ((int64_t)img * G + gA) * 2);
+            int g_prev = gA;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / cpg;
-            ga[e] = gamma[c + e]; be[e] = beta[c + e];
-            mean[e] = stats[((int64_t)img * G + grp) * 2]; rstd[e] = stats[((int64_t)img * G + grp) * 2 + 1];
+            for (int e = 0; e < 8; ++e) {
+                const int grp = (c + e) / cpg;
+                if (grp != g_prev) { st_prev = *reinterpret_cast<const float2*>(stats + ((int64_t)img * G + grp) * 2); g_prev = grp; }
+                mean[e] = st_prev.x; rstd[e] = st_prev.y;
+            }
         }
-        float a1[8] = {}, a2[8] = {}, dg[8] = {}, db[8] = {};
+        MDM_T(ts1 = nstamp_now();)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (lane + i * PL < P) {
@@ -388,35 +440,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
                     float xh = (xv[e] - mean[e]) * rstd[e];
                     float gz = dv[e];
                     if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
-                    dg[e] = fmaf(gz, xh, dg[e]); db[e] += gz;
+                    part[16 + e] = fmaf(gz, xh, part[16 + e]); part[24 + e] += gz;          // dgamma, dbeta
                     float gg = gz * ga[e];
-                    a1[e] += gg; a2[e] = fmaf(gg, xh, a2[e]);
+                    part[e] += gg; part[8 + e] = fmaf(gg, xh, part[8 + e]);                  // group sums
                 }
             }
         }
-        const bool pow2 = (VB & (VB - 1)) == 0 && VB * PL == 256;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
-            if (pow2) {
-                float r1 = lanes_sum(a1[e], VB), r2 = lanes_sum(a2[e], VB), r3 = lanes_sum(dg[e], VB), r4 = lanes_sum(db[e], VB);
-                if ((t & 63) < VB) {
-                    atomicAdd(&gsum[2 * gl], r1); atomicAdd(&gsum[2 * gl + 1], r2);
-                    atomicAdd(&chan[v * 8 + e], r3); atomicAdd(&chan[CBLK + v * 8 + e], r4);
-                }
-            } else {
-                atomicAdd(&gsum[2 * gl], a1[e]);
-                atomicAdd(&gsum[2 * gl + 1], a2[e]);
-                atomicAdd(&chan[v * 8 + e], dg[e]);
-                atomicAdd(&chan[CBLK + v * 8 + e], db[e]);
-            }
-        }
+    }
+    block_colsum<32>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
+    MDM_T(const unsigned long long ts2 = nstamp_now();)
+    if (t < CBLK && cb + t < C) {
+        const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
+        atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
+        atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
+        atomicAdd(&dgamma[cb + t], csum[(16 + e) * VB + vv]);
+        atomicAdd(&dbeta[cb + t], csum[(24 + e) * VB + vv]);
     }
     __syncthreads();
-    if (t < CBLK && cb + t < C) {
-        atomicAdd(&dgamma[cb + t], chan[t]);
-        atomicAdd(&dbeta[cb + t], chan[CBLK + t]);
-    }
+    MDM_T(const unsigned long long ts3 = nstamp_now(); const unsigned long long ts4 = ts3;)
     float k1[8], k2[8], ag[8];
     if (on) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
@@ -428,15 +469,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
             ag[e] = rstd[e] * ga[e];
         }
     }
-    if (sum_img || sum_all) {
-        __syncthreads();
-        if (t < 128) gsum[t] = 0.f;
-        __syncthreads();
-    }
+    float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (on) {
         bf16_t* dst; int acc, cc, CS;
         if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
-        float sx[8] = {};
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             int p = lane + i * PL;
@@ -464,24 +500,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
                 store8(q, r);
             }
         }
-        if (sum_img || sum_all) {
-            const bool pow2 = (VB & (VB - 1)) == 0 && VB * PL == 256;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (pow2) {
-                    float r = lanes_sum(sx[e], VB);
-                    if ((t & 63) < VB) atomicAdd(&gsum[(v * 8 + e)], r);
-                } else atomicAdd(&gsum[(v * 8 + e)], sx[e]);
-            }
-        }
     }
-    if (sum_img || sum_all) {
-        __syncthreads();
+    if (sum_img || sum_all) {            // uniform
+        block_colsum<8>(sx, scratch, csum, t, VB, PL);
         if (t < CBLK && cb + t < C) {
-            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = gsum[t];
-            if (sum_all) atomicAdd(&sum_all[cb + t], gsum[t]);
+            const float r = csum[(t & 7) * VB + (t >> 3)];
+            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = r;
+            if (sum_all) atomicAdd(&sum_all[cb + t], r);
         }
     }
+#ifdef MDM_STAMP
+    {
+        const unsigned long long ts5 = nstamp_now();
+        const unsigned widx = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (t >> 6);
+        if ((t & 63) == 0 && widx < 4096) {
+            unsigned long long* r = g_nstamp_buf + widx * 16;
+            r[0] = 1; r[1] = ts1 - ts0; r[2] = ts2 - ts1; r[3] = ts3 - ts2; r[4] = ts4 - ts3; r[5] = ts5 - ts4; r[6] = ts0; r[7] = ts5;
+        }
+    }
+#endif
 }
 
 // ---- row softmax: one wave per row
@@ -727,6 +764,17 @@ extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const
                                          (T*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all));
     return launch_status("groupnorm_bwd");
 }
+
+#ifdef MDM_STAMP
+extern "C" int mdm_debug_stamps_norm(unsigned long long* out, int reset) {      // out: 4096 * 16 entries
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdm::g_nstamp_buf), 4096 * 16 * 8) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mdm::g_nstamp_buf)) != hipSuccess || hipMemset(p, 0, 4096 * 16 * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int mdm_softmax_fwd(int dtype, void* S, int rows, int L, void* stream) {
     MDM_REQUIRE(rows > 0 && L > 0, "softmax: bad shape");
