@@ -102,14 +102,16 @@ int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)
  * x = concat(src0[C0], src1[C1]) along channels, NHWC, P = H*W pixels per image.
- * stats: [N][G][2] fp32 (mean, rstd).  One kernel per call (two passes over an L2-resident slice);
- * `ws` is unused and may be NULL (kept for ABI stability).
+ * stats: [N][G][2] fp32 (mean, rstd).  One kernel per call; with `ws` (fp32 scratch of >= N*32*G*2 floats, may
+ * be NULL) maps too large for one workgroup per (image, channel block) to pull HBM bandwidth are cut into pixel
+ * chunks: a statistics launch (partials in ws, fixed summation order) and an apply launch.
  * ------------------------------------------------------------------------- */
 int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1,
                       int N, int P, int G, float eps, const float* gamma, const float* beta,
                       int silu, void* y, float* stats, float* ws, void* stream);
 /* dx -> dst0/dst1 (channel split like the sources), acc flags add into them;
- * dgamma/dbeta are ACCUMULATED (one fp32 atomic per channel per image).  `ws` unused. */
+ * dgamma/dbeta are ACCUMULATED (one fp32 atomic per channel per image).  `ws` (may be NULL): fp32 scratch of
+ * >= N*32*G*2 floats; with it large maps are cut into pixel chunks (statistics launch + apply launch). */
 int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1,
                       int N, int P, int G, const float* gamma, const float* beta, int silu,
                       const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
@@ -121,7 +123,8 @@ int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int
 int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1,
                            int N, int P, int G, const float* gamma, const float* beta, int silu,
                            const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
-                           float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, void* stream);
+                           float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, float* ws,
+                           void* stream);
 
 /* row softmax of S[rows][L] in place (unet6.py:320-322), and its backward
  * dS = P * (dP - sum_j dP*P) written over dP. */

@@ -295,20 +295,31 @@ __device__ __forceinline__ unsigned long long nstamp_now() {
 #define MDM_T(...)
 #endif
 
-template <int NP>
+// MODE 0: the whole GroupNorm in one workgroup per (image, channel block).  Large maps leave too few such
+// workgroups to pull HBM bandwidth (128 for a 32x32x128 map: 14/24 us fwd/bwd against ~6/9 us of traffic),
+// so there the pixels are cut into gridDim.z chunks: MODE 1 = statistics of one chunk -> partials in ws
+// [image][chunk][group][2] (plain stores, nothing to zero, fixed summation order), MODE 2 = apply.
+template <int NP, int MODE>
 __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          float eps, const float* gamma, const float* beta, int silu, bf16_t* y,
-                                                         float* stats) {
+                                                         float* stats, float* ws) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
     const int img = blockIdx.y, cb = blockIdx.x * CBLK;
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
+    const int chunks = gridDim.z, chunk = blockIdx.z;
+    const int plen = (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
     __shared__ float scratch[16 * CS_PITCH];
     __shared__ float csum[16 * 8];
     __shared__ float gsum[2 * 64], gmean[64], grstd[64];
-    if (t < 2 * ng) gsum[t] = 0.f;
+    if (t < 2 * ng) {
+        float a = 0.f;
+        if (MODE == 2)
+            for (int ch = 0; ch < chunks; ++ch) a += ws[(((int64_t)img * chunks + ch) * G + g0 + (t >> 1)) * 2 + (t & 1)];
+        gsum[t] = a;
+    }
     const int64_t base = (int64_t)img * P;
     uint4 cx[NP];
     float part[16];
@@ -317,15 +328,17 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     if (on) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int p = lane + i * PL;
-            cx[i] = p < P ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
+            int p = pbeg + lane + i * PL;
+            cx[i] = p < pend ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
         }
+    }
+    if (MODE != 2 && on) {
         float K[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, (c + e) / cpg, cpg);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (lane + i * PL < P) {
+            if (pbeg + lane + i * PL < pend) {
                 float8 x = unpack8(cx[i]);
                 float xv[8] = F8_TO_ARR(x);
 #pragma unroll
@@ -333,13 +346,19 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
             }
         }
     }
-    block_colsum<16>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
-    if (t < CBLK && cb + t < C) {
-        const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
-        atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
-        atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
+    if (MODE != 2) {
+        block_colsum<16>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
+        if (t < CBLK && cb + t < C) {
+            const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
+            atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
+            atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
+        }
     }
     __syncthreads();
+    if (MODE == 1) {
+        if (t < 2 * ng && g0 + (t >> 1) < G) ws[(((int64_t)img * chunks + chunk) * G + g0 + (t >> 1)) * 2 + (t & 1)] = gsum[t];
+        return;
+    }
     if (t < ng && (g0 + t) < G) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
         float K = gn_pivot(s0, s1, C0, C1, base, g0 + t, cpg);
@@ -347,8 +366,10 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
         float var = fmaxf(gsum[2 * t + 1] * inv_cnt - md * md, 0.f);
         float mean = K + md, rstd = rsqrtf(var + eps);
         gmean[t] = mean; grstd[t] = rstd;
-        stats[((int64_t)img * G + g0 + t) * 2] = mean;
-        stats[((int64_t)img * G + g0 + t) * 2 + 1] = rstd;
+        if (chunk == 0) {
+            stats[((int64_t)img * G + g0 + t) * 2] = mean;
+            stats[((int64_t)img * G + g0 + t) * 2 + 1] = rstd;
+        }
     }
     __syncthreads();
     if (on) {
@@ -364,8 +385,8 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int p = lane + i * PL;
-            if (p < P) {
+            int p = pbeg + lane + i * PL;
+            if (p < pend) {
                 float8 x = unpack8(cx[i]);
                 float xv[8] = F8_TO_ARR(x);
                 float o[8];
@@ -381,22 +402,30 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     }
 }
 
-template <int NP>
+template <int NP, int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          const float* gamma, const float* beta, int silu, const bf16_t* dy,
                                                          const float* stats, bf16_t* d0, int acc0, bf16_t* d1, int acc1,
-                                                         float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
+                                                         float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all,
+                                                         float* ws) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
     const int img = blockIdx.y, cb = blockIdx.x * CBLK;
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
+    const int chunks = gridDim.z, chunk = blockIdx.z;
+    const int plen = (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
     __shared__ float scratch[32 * CS_PITCH];
     __shared__ float csum[32 * 8];
     __shared__ float gsum[2 * 64];
     MDM_T(const unsigned long long ts0 = nstamp_now();)
-    if (t < 2 * ng) gsum[t] = 0.f;
+    if (t < 2 * ng) {
+        float a = 0.f;
+        if (MODE == 2)
+            for (int ch = 0; ch < chunks; ++ch) a += ws[(((int64_t)img * chunks + ch) * G + g0 + (t >> 1)) * 2 + (t & 1)];
+        gsum[t] = a;
+    }
     const int64_t base = (int64_t)img * P;
     uint4 cx[NP], cd[NP];
     float ga[8], be[8], mean[8], rstd[8];
@@ -407,8 +436,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
     if (on) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int p = lane + i * PL;
-            bool ok = p < P;
+            int p = pbeg + lane + i * PL;
+            bool ok = p < pend;
             cx[i] = ok ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
             cd[i] = ok ? *reinterpret_cast<const uint4*>(dy + (base + p) * C + c) : make_uint4(0, 0, 0, 0);
         }
@@ -429,9 +458,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
             }
         }
         MDM_T(ts1 = nstamp_now();)
+        if (MODE != 2) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (lane + i * PL < P) {
+            if (pbeg + lane + i * PL < pend) {
                 float8 x = unpack8(cx[i]), d = unpack8(cd[i]);
                 float xv[8] = F8_TO_ARR(x);
                 float dv[8] = F8_TO_ARR(d);
@@ -446,17 +476,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
                 }
             }
         }
+        }
     }
-    block_colsum<32>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
+    if (MODE != 2) {
+        block_colsum<32>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
+        if (t < CBLK && cb + t < C) {
+            const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
+            atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
+            atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
+            atomicAdd(&dgamma[cb + t], csum[(16 + e) * VB + vv]);
+            atomicAdd(&dbeta[cb + t], csum[(24 + e) * VB + vv]);
+        }
+    }
     MDM_T(const unsigned long long ts2 = nstamp_now();)
-    if (t < CBLK && cb + t < C) {
-        const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
-        atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
-        atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
-        atomicAdd(&dgamma[cb + t], csum[(16 + e) * VB + vv]);
-        atomicAdd(&dbeta[cb + t], csum[(24 + e) * VB + vv]);
-    }
     __syncthreads();
+    if (MODE == 1) {
+        if (t < 2 * ng && g0 + (t >> 1) < G) ws[(((int64_t)img * chunks + chunk) * G + g0 + (t >> 1)) * 2 + (t & 1)] = gsum[t];
+        if (sum_img && chunk == 0 && t < CBLK && cb + t < C) sum_img[(int64_t)img * sum_ld + cb + t] = 0.f;
+        return;
+    }
     MDM_T(const unsigned long long ts3 = nstamp_now(); const unsigned long long ts4 = ts3;)
     float k1[8], k2[8], ag[8];
     if (on) {
@@ -475,8 +513,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
         if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            int p = lane + i * PL;
-            if (p < P) {
+            int p = pbeg + lane + i * PL;
+            if (p < pend) {
                 float8 x = unpack8(cx[i]), d = unpack8(cd[i]);
                 float xv[8] = F8_TO_ARR(x);
                 float dv[8] = F8_TO_ARR(d);
@@ -505,7 +543,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
         block_colsum<8>(sx, scratch, csum, t, VB, PL);
         if (t < CBLK && cb + t < C) {
             const float r = csum[(t & 7) * VB + (t >> 3)];
-            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = r;
+            if (sum_img) {
+                if (MODE == 0) sum_img[(int64_t)img * sum_ld + cb + t] = r;         // single writer
+                else atomicAdd(&sum_img[(int64_t)img * sum_ld + cb + t], r);        // zeroed by the MODE 1 launch
+            }
             if (sum_all) atomicAdd(&sum_all[cb + t], r);
         }
     }
@@ -697,6 +738,9 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
 // channels per workgroup: whole groups, whole 16-byte vectors, at least 32 channels
 static int g_gn_regs = []() { const char* e = getenv("MDM_GN_REGS"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_gn_minc = []() { const char* e = getenv("MDM_GN_MINC"); return e ? atoi(e) : 32; }();
+// pixel-chunked statistics + apply launches: measured no faster than the single launch at cfg2 (13.4 vs 13.7 us
+// forward, 25.3 vs 24.1 us backward on 32x32x128: two ~5 us launch floors eat the bandwidth gain) -> opt-in
+static int g_gn_split = []() { const char* e = getenv("MDM_GN_SPLIT"); return (e && e[0] == '1') ? 1 : 0; }();
 static int gn_cblk(int C, int G, int N, int P) {
     int cpg = C / G, l = cpg;
     while (l % 8) l += cpg;            // lcm(cpg, 8)
@@ -709,14 +753,22 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
                                  float eps, const float* gamma, const float* beta, int silu, void* y, float* stats,
                                  float* ws, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
-    (void)ws;
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     dim3 grid(cdiv(C, cblk), N);
     const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane
+    const int chunks = cdiv(np, 4);
+    if (dtype == MDM_BF16 && g_gn_regs && g_gn_split && ws && np > 4 && chunks <= 32 && (int64_t)grid.x * grid.y < 512) {
+        dim3 g3(grid.x, grid.y, chunks);                 // chunk length P/chunks <= 4 vectors per lane
+#define GN_FWD_SPLIT(M) hipLaunchKernelGGL((gn_fwd_reg_kernel<4, M>), g3, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                           (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
+        GN_FWD_SPLIT(1); GN_FWD_SPLIT(2);
+#undef GN_FWD_SPLIT
+        return launch_status("groupnorm_fwd");
+    }
     if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
-#define GN_FWD_REG(NPV) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
-                                           (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats)
+#define GN_FWD_REG(NPV) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                           (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
         if (np <= 1) GN_FWD_REG(1); else if (np <= 2) GN_FWD_REG(2); else if (np <= 4) GN_FWD_REG(4);
         else if (np <= 8) GN_FWD_REG(8); else GN_FWD_REG(16);
 #undef GN_FWD_REG
@@ -730,30 +782,40 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
 extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                       const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                       void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta,
-                                      float* sum_img, int sum_ld, float* sum_all, void* stream);
+                                      float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream);
 
 extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                  const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                  void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta, float* ws,
                                  void* stream) {
     return mdm_groupnorm_bwd_sums(dtype, src0, C0, src1, C1, N, P, G, gamma, beta, silu, dy, stats, dst0, acc0, dst1, acc1,
-                                  dgamma, dbeta, nullptr, 0, nullptr, stream);
+                                  dgamma, dbeta, nullptr, 0, nullptr, ws, stream);
 }
 
 extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                       const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                       void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta,
-                                      float* sum_img, int sum_ld, float* sum_all, void* stream) {
+                                      float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     MDM_REQUIRE(!(sum_img || sum_all) || (acc0 == 0 && C1 == 0), "groupnorm_bwd_sums: column sums need a plain (non-accumulating, single-source) dx");
     dim3 grid(cdiv(C, cblk), N);
     const int np = cdiv(P, 256 / (cblk / 8));
-    if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
-#define GN_BWD_REG(NPV) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+    const int chunks = cdiv(np, 4);
+    if (dtype == MDM_BF16 && g_gn_regs && g_gn_split && ws && np > 4 && chunks <= 32 && (int64_t)grid.x * grid.y < 512) {
+        dim3 g3(grid.x, grid.y, chunks);
+#define GN_BWD_SPLIT(M) hipLaunchKernelGGL((gn_bwd_reg_kernel<4, M>), g3, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
                                            (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
-                                           (bf16_t*)dst0, acc0, (bf16_t*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all)
+                                           (bf16_t*)dst0, acc0, (bf16_t*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all, ws)
+        GN_BWD_SPLIT(1); GN_BWD_SPLIT(2);
+#undef GN_BWD_SPLIT
+        return launch_status("groupnorm_bwd");
+    }
+    if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
+#define GN_BWD_REG(NPV) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                           (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
+                                           (bf16_t*)dst0, acc0, (bf16_t*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all, ws)
         if (np <= 1) GN_BWD_REG(1); else if (np <= 2) GN_BWD_REG(2); else if (np <= 4) GN_BWD_REG(4);
         else if (np <= 8) GN_BWD_REG(8); else GN_BWD_REG(16);
 #undef GN_BWD_REG

@@ -40,7 +40,7 @@ _PROTOS = {
     "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
-    "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp], i32),
+    "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], i32),
     "mdm_softmax_fwd": ([i32, vp, i32, i32, vp], i32),
     "mdm_softmax_bwd": ([i32, vp, vp, i32, i32, vp], i32),
     "mdm_timestep_embedding": ([vp, i32, i32, vp, vp], i32),

@@ -119,7 +119,7 @@ def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, ds
                   dgamma, dbeta, ws, G=32, sum_img=None, sum_ld=0, sum_all=None):
     call("mdm_groupnorm_bwd_sums", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
          ptr(stats), ptr(dst0), int(acc0), ptr(dst1), int(acc1), ptr(dgamma), ptr(dbeta), ptr(sum_img), sum_ld,
-         ptr(sum_all), stream())
+         ptr(sum_all), ptr(ws), stream())
 
 
 def softmax_fwd(dt, S, rows, L):

@@ -219,7 +219,9 @@ def test_batched_matmul_layouts(dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("C0,C1,HW,silu", [(128, 0, 64, True), (256, 128, 16, True), (32, 0, 256, False), (64, 32, 64, True)])
+@pytest.mark.parametrize("C0,C1,HW,silu", [(128, 0, 64, True), (256, 128, 16, True), (32, 0, 256, False), (64, 32, 64, True),
+                                           # large maps: pixel chunks (statistics launch + apply launch) on the bf16 path
+                                           (128, 0, 1024, True), (64, 32, 1024, True), (32, 0, 576, False)])
 def test_groupnorm_fwd_bwd(dt, C0, C1, HW, silu):
     from mdm import ops
     N, G = 3, 32
