@@ -95,9 +95,20 @@ typedef struct mdm_gemm_desc {
      * sum of dY, which the weight-gradient kernel already holds as MFMA fragments: one extra MFMA against
      * a ones-fragment per k-step in the tap-0 / first-column workgroups, fp32 atomics at the end). */
     float* dbias;
+    /* split-K through ws: 1 = do NOT launch the summing kernel; the (ws, splits, D0) triple is queued in the
+     * library and summed by the next mdm_splitk_reduce_pending() -- ONE launch for every queued contraction
+     * (the weight gradients of a whole backward chunk) instead of one ~5 us launch each.  ws must stay
+     * untouched until then (give every deferred call its own slice). */
+    int32_t defer_reduce; int32_t _p2;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
+/* Sums every queued split-K partial (see defer_reduce) into its destination and empties the queue.
+ * The queue is per host thread; queue and launch must be recorded/captured in the same order they are replayed. */
+int mdm_splitk_reduce_pending(void* stream);
+/* What mdm_gemm would choose for this descriptor given unlimited workspace: the split count and the
+ * workspace bytes it needs (0 when it would not use partial slabs).  No launch. */
+int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)

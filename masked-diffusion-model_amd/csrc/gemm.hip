@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <vector>
 
 namespace mdm {
 
@@ -220,6 +221,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
         }
         float4* q = reinterpret_cast<float4*>(D) + i;
         if (acc) { float4 o = *q; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *q = a;
+    }
+}
+
+// The same sum for MANY contractions in one launch (mdm_splitk_reduce_pending): the table travels by value in
+// the kernel arguments (a hipGraph keeps its own copy), a workgroup finds its segment by a scan of the
+// prefix of workgroup counts.
+struct ReduceSeg { const float* ws; float* D; long long total4; int splitk, acc; };
+constexpr int REDUCE_MAX_SEGS = 96;
+struct ReduceTable { int n; int first_block[REDUCE_MAX_SEGS + 1]; ReduceSeg seg[REDUCE_MAX_SEGS]; };
+constexpr int REDUCE_VEC_PER_BLOCK = 1024;          // float4 per workgroup
+__global__ __launch_bounds__(256) void splitk_reduce_batched_kernel(ReduceTable tab) {
+    int si = 0;
+    while (si + 1 < tab.n && (int)blockIdx.x >= tab.first_block[si + 1]) ++si;
+    const ReduceSeg sg = tab.seg[si];
+    const long long base = (long long)(blockIdx.x - tab.first_block[si]) * REDUCE_VEC_PER_BLOCK;
+#pragma unroll
+    for (int r = 0; r < REDUCE_VEC_PER_BLOCK / 256; ++r) {
+        const long long i = base + r * 256 + threadIdx.x;
+        if (i >= sg.total4) break;
+        float4 a = reinterpret_cast<const float4*>(sg.ws)[i];
+        for (int s = 1; s < sg.splitk; ++s) {
+            float4 b = reinterpret_cast<const float4*>(sg.ws)[(long long)s * sg.total4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float4* q = reinterpret_cast<float4*>(sg.D) + i;
+        if (sg.acc) { float4 o = *q; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
         *q = a;
     }
 }
@@ -1333,6 +1361,154 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
 #endif
 }
 
+
+// ----------------------------------------------------------------------------
+// wgrad_lin: weight gradient of a stride-1 "same" convolution (layout 2: k = output pixel, rows of both
+// operands are pixels), the counterpart of conv_lin2 for the backward-weights pass.  gemm_ring_kernel decodes
+// (image, y, x) and gathers the source pixel per lane per piece per slab; here the input pixel of tap
+// (ty, tx) is LINEAR in the reduction index (p_in = p_out + (ty - pad_t) * W + tx - pad_l), a slab is 64
+// consecutive pixels = 64 / W whole image rows, so a lane's x never changes and its y advances by a constant:
+// one live pointer per piece (+= a constant per slab) and ~6 VALU of validity per gathered piece.
+// Requires: stride 1, no upsample, IH == OH, IW == OW, 64 % OW == 0, OH a power of two, K % 64 == 0.
+// ----------------------------------------------------------------------------
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
+    constexpr int BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;
+    constexpr int ACPR = BM / 8, BCPR = BN / 8, A_RPP = 64 / ACPR, B_RPP = 64 / BCPR;
+    constexpr int WROWS = NW / 2;
+    constexpr int WM = BM / WROWS, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const ZInfo z = decode_z(d, BK);
+    const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+    const int ty = z.tap / d.KW, tx = z.tap - ty * d.KW;
+    const int dyy = ty - d.pad_t, dxx = tx - d.pad_l;
+    const int rows_per_slab = BK / d.OW;
+    const int nk = (z.kend - z.kbeg) / BK;
+
+    // ---- A = dY[k][m]: [64][BM] image, piece = A_RPP k-rows
+    const char* pa[GA];
+    const int64_t a_step = (int64_t)BK * d.lda * 2;
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        const int kl = (wave * GA + j) * A_RPP + lane / ACPR;
+        const int gm = m0 + 8 * ((lane % ACPR) ^ swz_cols<ACPR>(kl));
+        pa[j] = (gm < d.M && nk > 0) ? reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.A) + (int64_t)(z.kbeg + kl) * d.lda + gm) : zlane;
+        if (!(gm < d.M)) pa[j] = zlane;
+    }
+    bool a_live[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) a_live[j] = pa[j] != zlane;
+    // ---- B = gathered input pixels [k][n]
+    const char* pb[GB];         // pointer to the SHIFTED source pixel of the current slab (may be out of the image: see b_val)
+    int b_y[GB];                // y of this lane's output pixel in the current slab
+    int b_step[GB];             // bytes per slab (depends on the source the lane's channels come from)
+    bool b_xok[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int kl = (wave * GB + j) * B_RPP + lane / BCPR;
+        const int gn = n0 + 8 * ((lane % BCPR) ^ swz_cols<BCPR>(kl));
+        const int k = z.kbeg + kl;
+        const int x = k % d.OW, y = (k / d.OW) & (d.OH - 1);
+        b_y[j] = y;
+        b_xok[j] = gn < d.N && (unsigned)(x + dxx) < (unsigned)d.OW && !(d._p0 & 2);
+        const bool s1 = gn >= d.C0;
+        const int ld = s1 ? d.ld1 : d.ld0;
+        const bf16_t* S = reinterpret_cast<const bf16_t*>(s1 ? d.src1 : d.src0);
+        b_step[j] = BK * ld * 2;
+        pb[j] = reinterpret_cast<const char*>(S + ((int64_t)k + dyy * d.OW + dxx) * ld + (s1 ? gn - d.C0 : gn));
+    }
+
+    int issued = 0, i_stage = 0;
+    auto issue = [&]() {
+        char* stage = ring + i_stage;
+        const bool live = issued < nk;
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+            lds_dma16((live && a_live[j]) ? pa[j] : zlane, stage + (wave * GA + j) * 1024);
+            pa[j] += a_step;
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const bool ok = live && b_xok[j] && (unsigned)(b_y[j] + dyy) < (unsigned)d.OH;
+            lds_dma16(ok ? pb[j] : zlane, stage + A_BYTES + (wave * GB + j) * 1024);
+            pb[j] += b_step[j];
+            b_y[j] = (b_y[j] + rows_per_slab) & (d.OH - 1);
+        }
+        ++issued;
+        i_stage += STAGE_BYTES;
+        if (i_stage == NSTAGE * STAGE_BYTES) i_stage = 0;
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = d.dbias != nullptr && z.outer == 0 && n0 == 0 && wc == 0;
+    f32x4 accb[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+
+#pragma unroll
+    for (int s2 = 0; s2 < NSTAGE - 1; ++s2) issue();
+    int c_stage = 0;
+    for (int it = 0; it < nk; ++it) {
+        wait_vmcnt<(NSTAGE - 2) * G>();
+        __builtin_amdgcn_s_barrier();
+        issue();
+        const char* As = ring + c_stage;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = ring_frag_cols<ACPR>(As, wr * WM + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = ring_frag_cols<BCPR>(Bs, wc * WN + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+            }
+        }
+        c_stage += STAGE_BYTES;
+        if (c_stage == NSTAGE * STAGE_BYTES) c_stage = 0;
+    }
+    wait_vmcnt<0>();
+    if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            int m = m0 + wr * WM + i * 16 + (lane & 15);
+            if (m < d.M) atomicAdd(&d.dbias[m], accb[i][0]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = m0 + wr * WM + i * 16 + (lane & 15);
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // host launch
 // ----------------------------------------------------------------------------
@@ -1426,6 +1602,23 @@ static int launch_lin2(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     return 0;
 }
 
+template <int BM, int BN, int NSTAGE, int NW>
+static int launch_wgrad_lin(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lin_kernel<BM, BN, NSTAGE, NW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((wgrad_lin_kernel<BM, BN, NSTAGE, NW>), grid, dim3(64 * NW), bytes, s, d);
+    return 0;
+}
+static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
+    return d.dtype == MDM_BF16 && d.layout == 2 && d.conv && d.stride == 1 && d.ups == 0 && d.IH == d.OH && d.IW == d.OW &&
+           d.OW > 0 && 64 % d.OW == 0 && (d.OH & (d.OH - 1)) == 0 && d.K % 64 == 0 && d.C0 % 8 == 0 && d.C1 % 8 == 0;
+}
+
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
@@ -1456,11 +1649,37 @@ static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES");
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
+static int g_wgrad_lin = []() { const char* e = getenv("MDM_WGRAD_LIN"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
 
-int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
+static thread_local std::vector<ReduceSeg> g_pending;
+
+int reduce_pending(hipStream_t s) {
+    size_t i = 0;
+    while (i < g_pending.size()) {
+        ReduceTable tab;
+        tab.n = 0;
+        int blocks = 0;
+        while (i < g_pending.size() && tab.n < REDUCE_MAX_SEGS) {
+            const ReduceSeg& sg = g_pending[i];
+            const long long nb = (sg.total4 + REDUCE_VEC_PER_BLOCK - 1) / REDUCE_VEC_PER_BLOCK;
+            if (blocks + nb > (1ll << 30)) break;
+            tab.first_block[tab.n] = blocks;
+            tab.seg[tab.n++] = sg;
+            blocks += (int)nb;
+            ++i;
+        }
+        tab.first_block[tab.n] = blocks;
+        if (blocks > 0) hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab);
+    }
+    g_pending.clear();
+    return launch_status("splitk reduce (batched)");
+}
+
+int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullptr, int64_t* plan_ws = nullptr) {
     MDM_REQUIRE(dh != nullptr, "gemm: null descriptor");
     mdm_gemm_desc d = *dh;
+    if (plan_splitk) { d.ws = reinterpret_cast<void*>(16); d.ws_bytes = (int64_t)1 << 60; }   // "unlimited": never dereferenced
     if (d.N0 == 0) d.N0 = d.N;
     d._p0 = g_dbg_flags;        // timing experiments only (bit 0: A operand from the zero page, bit 1: B operand)
     if (int rc = validate(d)) return rc;
@@ -1504,6 +1723,11 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     } else {
         d.ws = nullptr;
     }
+    if (plan_splitk) {
+        *plan_splitk = d.splitk;
+        *plan_ws = (d.ws && d.splitk > 1) ? (tap_split ? (int64_t)d.splitk * d.M * d.N * 4 : slab * d.splitk) : 0;
+        return 0;
+    }
     MDM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
     dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * d.splitk));
     MDM_REQUIRE(grid.z <= 65535, "gemm: grid.z=%u too large", grid.z);
@@ -1538,6 +1762,9 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
                  : g_lin2 == 3 ? launch_lin2<64, 64, 4, 4, 2, 1, true>(d, grid, s) : launch_lin2<64, 64, 4, 4, 2, 1>(d, grid, s);
         }
         if (rc) return rc;
+    } else if (g_use_ring && g_wgrad_lin && wgrad_lin_eligible(d)) {
+        int rc = big ? launch_wgrad_lin<128, 128, 3, 8>(d, grid, s) : launch_wgrad_lin<64, 64, 4, 8>(d, grid, s);
+        if (rc) return rc;
     } else if (g_use_ring && ring_eligible(d)) {
         int rc = big ? (g_big_waves == 16 ? launch_ring<128, 128, 3, 16>(d, grid, s) : g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
                                          : launch_ring<128, 128, 3>(d, grid, s))
@@ -1553,6 +1780,9 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         const int64_t total4 = (int64_t)d.M * d.N / 4;
         int64_t nb = (total4 + 255) / 256;
         hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t>), dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s, d);
+    } else if (d.splitk > 1 && d.ws && d.defer_reduce) {
+        g_pending.push_back(ReduceSeg{reinterpret_cast<const float*>(d.ws), reinterpret_cast<float*>(d.D0),
+                                      (long long)((int64_t)zouter * d.M * d.N / 4), d.splitk, d.acc0});
     } else if (d.splitk > 1 && d.ws) {
         const int64_t total4 = (int64_t)zouter * d.M * d.N / 4;
         int64_t nb = (total4 + 255) / 256;
@@ -1577,4 +1807,9 @@ extern "C" int mdm_debug_stamps(unsigned long long* out, int reset) {      // ou
 
 extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
     return mdm::gemm_launch(desc_host, mdm::pick_stream(stream));
+}
+extern "C" int mdm_splitk_reduce_pending(void* stream) { return mdm::reduce_pending(mdm::pick_stream(stream)); }
+extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
+    if (!splitk_out || !ws_bytes_out) { mdm::set_error("gemm_plan: null output"); return -1; }
+    return mdm::gemm_launch(desc_host, nullptr, splitk_out, ws_bytes_out);
 }

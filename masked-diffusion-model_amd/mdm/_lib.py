@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("src0", vp), ("src1", vp), ("ld0", i32), ("ld1", i32), ("wtap", i64),
         ("D0", vp), ("D1", vp), ("ldd0", i32), ("ldd1", i32), ("N0", i32), ("out_f32", i32), ("alpha", f32),
         ("acc0", i32), ("acc1", i32), ("bias", vp), ("rowvec", vp), ("rv_ld", i32), ("rows_per_img", i32),
-        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp),
+        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp), ("defer_reduce", i32), ("_p2", i32),
     ]
 
 
@@ -38,6 +38,8 @@ _PROTOS = {
     "mdm_version": ([], i32),
     "mdm_device_count": ([], i32),
     "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
+    "mdm_splitk_reduce_pending": ([vp], i32),
+    "mdm_gemm_plan": ([C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i64)], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], i32),
@@ -237,16 +239,35 @@ def torch_dtype(dt):
     return torch.float32 if dt == F32 else torch.bfloat16
 
 
-def gemm(**kw):
-    """Fill a descriptor from keyword fields (tensors become device pointers) and launch / record it."""
+def _desc(kw):
     d = GemmDesc()
     d.alpha = 1.0
     d.batch = 1
-    flops = kw.pop("_flops", None)
     for k, v in kw.items():
         if isinstance(v, torch.Tensor):
             v = v.data_ptr()
         setattr(d, k, v)
+    return d
+
+
+def gemm_plan(**kw):
+    """(split count, workspace bytes) mdm_gemm would use for these fields given unlimited workspace; no launch."""
+    kw.pop("_flops", None)
+    d = _desc(kw)
+    sk, nb = i32(), i64()
+    check(load().mdm_gemm_plan(C.byref(d), C.byref(sk), C.byref(nb)), "mdm_gemm_plan")
+    return sk.value, nb.value
+
+
+def reduce_call():
+    """A recorded-call entry for mdm_splitk_reduce_pending (appended to backward chunks cut out of a plan)."""
+    return ("mdm_splitk_reduce_pending", getattr(load(), "mdm_splitk_reduce_pending"), ())
+
+
+def gemm(**kw):
+    """Fill a descriptor from keyword fields (tensors become device pointers) and launch / record it."""
+    flops = kw.pop("_flops", None)
+    d = _desc(kw)
     if _recording is not None:
         _recording.keep.append((d, kw))
         # algorithmic FLOPs of this launch, keyed by its index in the recording (bench.py roofline)

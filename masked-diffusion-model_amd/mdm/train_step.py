@@ -172,7 +172,8 @@ class TrainStep:
         chunks, lo = [], 0
         for hi in cuts:
             r = _lib.Recording()
-            r.calls = m.backward_plan.calls[lo:hi]
+            r.calls = list(m.backward_plan.calls[lo:hi])
+            r.calls.append(_lib.reduce_call())      # the chunk's deferred split-K sums, before its bucket is exchanged
             r.keep = m.backward_plan.keep
             chunks.append(r)
             lo = hi

@@ -12,6 +12,7 @@ import math
 from collections import OrderedDict
 from types import SimpleNamespace
 
+import os
 import torch
 
 from . import _lib, ops
@@ -213,8 +214,12 @@ class _Conv:
         fuse_bias = n.dt == BF16 and self.fc_slot is None     # bias sums ride along in the weight-gradient kernel
         if not fuse_bias and not getattr(self, "sums_by_norm", False):
             ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
+        # split-K partials go to this conv's own slice of the arena; ONE kernel sums all of them at the end of
+        # the backward (or of a gradient-bucket chunk): UNet._emit_bwd / TrainStep._build_graphs
+        own = getattr(self, "wgrad_ws", None)
         ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"),
-                       ws=n.splitk_ws2 if fork else n.splitk_ws, dbias=st.g(self.name + ".bias") if fuse_bias else None)
+                       ws=own if own is not None else n.splitk_ws, dbias=st.g(self.name + ".bias") if fuse_bias else None,
+                       defer=own is not None)
         if fork:
             _lib.call("mdm_side_end", _lib.stream())
         if not s0.needs_grad:
@@ -559,7 +564,18 @@ class UNet:
         # split-K partial slabs of the weight-gradient contractions: room for 16 splits of the largest filter
         wmax = max(s.g.taps * s.g.Cout * s.g.Cin for s in self.specs if isinstance(s, _Conv))
         self.splitk_ws = self.alloc((16 * wmax,), torch.float32)
-        self.splitk_ws2 = self.splitk_ws       # side-branch weight gradients are serialised among themselves: one workspace
+        self.splitk_ws2 = self.splitk_ws
+        # weight gradients: every conv gets its own slice for its split-K partials (sized by the library's own
+        # split rule), so their sums can be deferred into one batched launch per backward chunk
+        need = [(s, ops.conv_wgrad_ws_bytes(self.dt, s.g)) for s in self.specs if isinstance(s, _Conv)]
+        total = sum((nb + 255) // 256 * 256 for _, nb in need)
+        if total and os.environ.get("MDM_DEFER_REDUCE", "1") != "0":
+            arena = self.alloc((total // 4,), torch.float32)
+            off = 0
+            for s, nb in need:
+                if nb:
+                    s.wgrad_ws = arena[off // 4:(off + nb) // 4]
+                    off += (nb + 255) // 256 * 256
         self.x_nchw = self.alloc((self.N, self.cin, self.H, self.W), torch.float32)
         self.y_nchw = self.alloc((self.N, self.cout, self.H, self.W), torch.float32)
 
@@ -583,6 +599,7 @@ class UNet:
         for s in reversed(self.specs):
             s.bwd()
             self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
+        ops.splitk_reduce_pending()         # the deferred split-K sums of every weight gradient above: one launch
 
     def census(self):
         """Leaf-op output elements of ONE forward under the counting rule of SURVEY 8(d) (every
