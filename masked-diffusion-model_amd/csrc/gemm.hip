@@ -107,6 +107,15 @@ __device__ __forceinline__ const T* gather_ptr(const mdm_gemm_desc& d, const Row
 
 struct ZInfo { int batch, tap, kbeg, kend, ks, outer; };
 
+// Workgroups are dealt to the 8 XCDs round-robin by linear id; each XCD has its own L2.  This bijection hands
+// XCD x the x-th CONTIGUOUS eighth of the work items instead, so items that read the same operand slices
+// (the filter taps and output tiles of one k-range; neighbouring pixel tiles and the column tiles of one
+// pixel tile) meet in one L2.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total >> 3, r = total & 7, x = lin & 7, w = lin >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
+}
+
 __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
     ZInfo z;
     z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K;
@@ -605,6 +614,37 @@ __device__ __forceinline__ bf16x8 ring_frag_cols(const char* tile, int col0, int
     return f;
 }
 
+
+// ds_read_b64_tr_b16 through inline asm.  hipcc orders the builtin form behind EVERY in-flight LDS-DMA of the
+// wave (it cannot prove the read and the global_load_lds destinations apart and emits s_waitcnt vmcnt(0) in
+// front of the first read: the whole prefetch ring collapses to "issue, then wait for it" -- 2100 cycles per
+// slab in the weight-gradient kernel against 1380 in the forward kernel that reads with plain ds_read_b128).
+// asm loads are invisible to the compiler's counters: the caller retires them with tr_wait() before use.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+struct TrFrag { v2u_t lo, hi; };
+template <int CPR>
+__device__ __forceinline__ void ring_frag_cols_issue(const char* tile, int col0, int ks, int lane, TrFrag& f) {
+    const int i = lane & 15;
+    const int kb = ks * 32 + 8 * (lane >> 4) + (i >> 2);
+    const int col = col0 + 4 * (i & 3);
+    const int ch = col >> 3, half = (col >> 2) & 1;
+    const char* p0 = tile + kb * (CPR * 16) + ((ch ^ swz_cols<CPR>(kb)) << 4) + half * 8;
+    const char* p1 = tile + (kb + 4) * (CPR * 16) + ((ch ^ swz_cols<CPR>(kb + 4)) << 4) + half * 8;
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p0;
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1) : "memory");
+}
+__device__ __forceinline__ void tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);          // nothing that consumes the fragments may move above the wait
+}
+__device__ __forceinline__ bf16x8 tr_value(const TrFrag& f) {
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    v4u_t v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // select without a branch: p if ok else the zero page
@@ -1086,7 +1126,8 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int tile_i = (d._p0 & 8) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // opt-in: measured no gain at cfg2
+    const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int sk = d.splitk < 1 ? 1 : d.splitk;
     ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.ks = blockIdx.z;
@@ -1380,13 +1421,23 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
     constexpr int WROWS = NW / 2;
     constexpr int WM = BM / WROWS, WN = BN / 2, MI = WM / 16, NI = WN / 16;
     extern __shared__ __attribute__((aligned(1024))) char ring[];
+    MDM_T(const unsigned long long t_entry = stamp_now();)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-    const ZInfo z = decode_z(d, BK);
+    // work item order: k-range major, then filter tap, then output tile -- a contiguous run per XCD (xcd_remap)
+    const int sk = d.splitk < 1 ? 1 : d.splitk, ntap = d.KH * d.KW, per_k = ntap * (int)gridDim.x;
+    int item = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z;
+    if (d._p0 & 8) item = xcd_remap(item, per_k * sk);        // measured: no gain at cfg2 (L2 hit rate is not the limiter)
+    const int ks_i = item / per_k, rem_i = item - ks_i * per_k, tap_i = rem_i / (int)gridDim.x, tile_i = rem_i - tap_i * (int)gridDim.x;
+    const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
+    ZInfo z; z.batch = 0; z.tap = tap_i; z.outer = tap_i; z.ks = ks_i; z.kbeg = 0; z.kend = d.K;
+    if (sk > 1) {
+        const int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
+        z.kbeg = ks_i * chunk; z.kend = min(d.K, z.kbeg + chunk);
+    }
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int ty = z.tap / d.KW, tx = z.tap - ty * d.KW;
     const int dyy = ty - d.pad_t, dxx = tx - d.pad_l;
@@ -1463,6 +1514,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int s2 = 0; s2 < NSTAGE - 1; ++s2) issue();
     int c_stage = 0;
+    MDM_T(const unsigned long long tstart = stamp_now();)
     for (int it = 0; it < nk; ++it) {
         wait_vmcnt<(NSTAGE - 2) * G>();
         __builtin_amdgcn_s_barrier();
@@ -1471,11 +1523,17 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
         const char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
+            TrFrag ta[MI], tb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) ring_frag_cols_issue<ACPR>(As, wr * WM + i * 16, ks, lane, ta[i]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ring_frag_cols_issue<BCPR>(Bs, wc * WN + j * 16, ks, lane, tb[j]);
+            tr_wait();
             bf16x8 af[MI], bfr[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = ring_frag_cols<ACPR>(As, wr * WM + i * 16, ks, lane);
+            for (int i = 0; i < MI; ++i) af[i] = tr_value(ta[i]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = ring_frag_cols<BCPR>(Bs, wc * WN + j * 16, ks, lane);
+            for (int j = 0; j < NI; ++j) bfr[j] = tr_value(tb[j]);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1490,6 +1548,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
         if (c_stage == NSTAGE * STAGE_BYTES) c_stage = 0;
     }
     wait_vmcnt<0>();
+    MDM_T(const unsigned long long t_loop_end = stamp_now();)
     if (do_bias && (lane >> 4) == 0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -1507,6 +1566,17 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
             if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
         }
     }
+#ifdef MDM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const unsigned widx = (blockIdx.z * gridDim.x + blockIdx.x) * NW + wave;
+        if (widx < 4096) {
+            unsigned long long* r = g_stamp_buf + widx * 32;
+            r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = nk > 0 ? nk : 0; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
+            r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
+        }
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------
