@@ -846,14 +846,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[MI], bfr[NI];
+            TrFrag ta[MI], tb[NI];          // k-strided operands: transposing reads through asm (see ring_frag_cols_issue)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = A_ROWS ? ring_frag_rows(As, wr * WM + i * 16, ks, lane)
-                               : ring_frag_cols<ACPR>(As, wr * WM + i * 16, ks, lane);
+            for (int i = 0; i < MI; ++i) {
+                if (A_ROWS) af[i] = ring_frag_rows(As, wr * WM + i * 16, ks, lane);
+                else ring_frag_cols_issue<ACPR>(As, wr * WM + i * 16, ks, lane, ta[i]);
+            }
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                bfr[j] = B_ROWS ? ring_frag_rows(Bs, wc * WN + j * 16, ks, lane)
-                                : ring_frag_cols<BCPR>(Bs, wc * WN + j * 16, ks, lane);
+            for (int j = 0; j < NI; ++j) {
+                if (B_ROWS) bfr[j] = ring_frag_rows(Bs, wc * WN + j * 16, ks, lane);
+                else ring_frag_cols_issue<BCPR>(Bs, wc * WN + j * 16, ks, lane, tb[j]);
+            }
+            if (!A_ROWS || !B_ROWS) {
+                tr_wait();
+#pragma unroll
+                for (int i = 0; i < MI; ++i) if (!A_ROWS) af[i] = tr_value(ta[i]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) if (!B_ROWS) bfr[j] = tr_value(tb[j]);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
