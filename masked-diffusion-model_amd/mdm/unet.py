@@ -208,7 +208,7 @@ class _Conv:
         # The parameter gradients (bias sums, weight gradient) and the data gradient only READ dy:
         # they run as two parallel branches (side stream / main stream) and meet again before anything
         # may overwrite dy (it can be aliased as the residual's gradient and accumulated into later).
-        fork = n.concurrent_bwd and s0.needs_grad
+        fork = s0.needs_grad and (n.concurrent_bwd == 1 or (n.concurrent_bwd == 2 and g.OH * g.OW <= 64))
         if fork:
             _lib.call("mdm_fork", _lib.stream())
         fuse_bias = n.dt == BF16 and self.fc_slot is None     # bias sums ride along in the weight-gradient kernel
@@ -383,7 +383,7 @@ class UNet:
         self._scratch = None
         self._scratch_n = 0
         self.use_graph = use_graph
-        self.concurrent_bwd = bool(int(__import__("os").environ.get("MDM_CONCURRENT_BWD", "0")))   # measured slower (10.96 vs 10.57 ms/step at cfg2)
+        self.concurrent_bwd = int(os.environ.get("MDM_CONCURRENT_BWD", "0"))    # 1: every conv, 2: only maps <= 8x8    # measured slower (10.96 vs 10.57 ms/step at cfg2)
         shared = store is not None
         self.store = store if shared else ParamStore()
         self._build_specs()
