@@ -1589,6 +1589,142 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
 #endif
 }
 
+
+// ----------------------------------------------------------------------------
+// conv_halo: 3x3 stride-1 "same" convolution (forward, and the data gradient through the transposed shadow)
+// with the INPUT TILE staged once per 64-channel slab and reused by all 9 filter taps.
+// Stamps on conv_lin2 (scripts/stamp_lin2.py) put a 128x128 slab at ~1400 cycles whatever the schedule
+// (pipelined, staggered wave groups): 32 KB of operands per slab against a per-CU LDS-DMA intake of
+// ~65 GB/s (27 B/clk) IS 1200 cycles -- the loop is bound by bytes fed to the CU, not by MFMA, LDS or L2.
+// An im2col gather feeds every input pixel 9 times.  Here a workgroup owns BM = R whole image rows x 64
+// output channels: the (R+2) x (W+2) halo of one 64-channel slab is DMA'd once (43 KB for 8 rows of 32)
+// and the 9 taps read it at shifted rows; only the 8-KB filter tile changes per tap.  Per tap-slab a wave
+// issues ~1.7 DMA pieces instead of 4 (13 KB per 2.1 MFLOP instead of 32 KB).
+//   LDS: 2 halo buffers (next slab lands while this one multiplies) + 4-stage ring of filter tiles.
+//   A fragment rows = halo rows hb(pixel) + tap shift: a per-lane table of 9 x MI LDS offsets (the
+//   XOR swizzle depends on the shifted row) built once.
+// Requires: KH = KW = 3, pads 1, stride 1, no upsample, IH = OH, IW = OW in {16, 32, 64}, BM % OW == 0,
+// (BM / OW) | OH, C0 % 64 == C1 % 64 == 0, N % 64 == 0.
+// ----------------------------------------------------------------------------
+template <int BM, int NPW>
+__global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
+    constexpr int BN = 64, NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, NSB = 4;
+    constexpr int B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int OW = d.OW, OH = d.OH, HW2 = OW + 2;
+    const int R = BM / OW, HR = (R + 2) * HW2, NPA = (HR + 7) >> 3, ABUF = NPA * 1024;
+    char* const bring = lds + 2 * ABUF;
+    char* const dummy = bring + NSB * B_BYTES;
+    const int tiles_n = d.N / BN;
+    const int mt = blockIdx.x / tiles_n, n0 = (blockIdx.x - mt * tiles_n) * BN, m0 = mt * BM;
+    const int img = m0 / (OH * OW), y0 = (m0 / OW) % OH;
+    const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+    const int NCS = d.Ck / 64;                       // 64-channel slabs over both sources
+    const int sgn = d.transposed ? -1 : 1;
+
+    // ---- halo pieces of this wave: piece p = wave + 8 k holds halo rows 8p .. 8p+7
+    int apix[NPW];
+    const int lch16 = ((lane & 7) ^ (lane >> 3)) << 4;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int hr = (wave + 8 * k) * 8 + (lane >> 3);
+        const int hy = hr / HW2, hx = hr - hy * HW2;
+        const int y = y0 - 1 + hy, x = hx - 1;
+        const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M && !(d._p0 & 1);
+        apix[k] = ok ? (img * OH + y) * OW + x : -1;
+    }
+    auto issue_a = [&](int k, int cs, char* abuf) {                 // k compile-time after unrolling
+        const int p = wave + 8 * k;
+        const int c = cs * 64;
+        const bool s1 = c >= d.C0;
+        const bf16_t* S = reinterpret_cast<const bf16_t*>(s1 ? d.src1 : d.src0);
+        const int ld = s1 ? d.ld1 : d.ld0, cc = s1 ? c - d.C0 : c;
+        const char* src = reinterpret_cast<const char*>(S + (int64_t)apix[k] * ld + cc) + lch16;
+        lds_dma16((apix[k] >= 0 && cs < NCS) ? src : zlane, p < NPA ? abuf + p * 1024 : dummy);
+    };
+    // ---- filter tile of (tap, slab): 64 rows (output channels) x 128 B, one piece per wave
+    const int bn = n0 + wave * 8 + (lane >> 3);
+    const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)bn * d.ldb) + lch16;
+    auto issue_b = [&](int tap, int cs, int stage) {
+        const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * 64) * 2;
+        lds_dma16((cs < NCS && !(d._p0 & 2)) ? b_row + off : zlane, bring + stage * B_BYTES + wave * 1024);
+    };
+
+    // ---- per-lane fragment offsets
+    int a_addr[9][MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = wr * WM + i * 16 + (lane & 15);
+        const int r = ml / OW, x = ml - r * OW;
+        const int hb = (r + 1) * HW2 + x + 1;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int ty = tp / 3, tx = tp - ty * 3;
+            const int hr = hb + sgn * (ty - 1) * HW2 + sgn * (tx - 1);
+            a_addr[tp][i] = hr * 128 + (((lane >> 4) ^ (hr & 7)) << 4);
+        }
+    }
+    int b_off[2][NI];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = wc * WN + j * 16 + (lane & 15);
+            b_off[ks][j] = nl * 128 + (((ks * 4 + (lane >> 4)) ^ (nl & 7)) << 4);
+        }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..2
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) issue_a(k, 0, lds);
+    issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
+
+    int a_cur = 0;                         // byte offset of the halo buffer being multiplied
+    int b_stage = 0;                       // ring stage of the current tap-slab
+#define MDM_HALO_A(tau) ((((tau) + 9) % 9) < NPW ? 1 : 0)
+#define MDM_HALO_TAP(T)                                                                                          \
+    {                                                                                                            \
+        /* everything up to and including the filter tile of this tap-slab has landed (issued 3 iterations ago) */ \
+        wait_vmcnt<2 + MDM_HALO_A(T - 3) + MDM_HALO_A(T - 2) + MDM_HALO_A(T - 1)>();                             \
+        __builtin_amdgcn_s_barrier();                                                                            \
+        issue_b(((T) + 3) % 9, cs + ((T) + 3) / 9, (b_stage + 3) & 3);                                           \
+        if ((T) < NPW) issue_a((T), cs + 1, lds + (a_cur ^ a_flip));                                             \
+        const char* As = lds + a_cur;                                                                            \
+        const char* Bs = bring + b_stage * B_BYTES;                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
+            bf16x8 af[MI], bfr[NI];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
+                af[i] = *reinterpret_cast<const bf16x8*>(As + (a_addr[T][i] ^ (ks << 6)));                       \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + b_off[ks][j]);                                    \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);      \
+        }                                                                                                        \
+        b_stage = (b_stage + 1) & 3;                                                                             \
+    }
+    const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
+    for (int cs = 0; cs < NCS; ++cs) {
+        MDM_HALO_TAP(0) MDM_HALO_TAP(1) MDM_HALO_TAP(2) MDM_HALO_TAP(3) MDM_HALO_TAP(4)
+        MDM_HALO_TAP(5) MDM_HALO_TAP(6) MDM_HALO_TAP(7) MDM_HALO_TAP(8)
+        a_cur = a_cur == 0 ? ABUF : 0;
+    }
+#undef MDM_HALO_TAP
+#undef MDM_HALO_A
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (m0 < d.M) { /* uniform */ }
+    epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+}
+
 // ----------------------------------------------------------------------------
 // host launch
 // ----------------------------------------------------------------------------
@@ -1699,6 +1835,37 @@ static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
            d.OW > 0 && 64 % d.OW == 0 && (d.OH & (d.OH - 1)) == 0 && d.K % 64 == 0 && d.C0 % 8 == 0 && d.C1 % 8 == 0;
 }
 
+template <int BM, int NPW>
+static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
+    const int R = BM / d.OW, HR = (R + 2) * (d.OW + 2), NPA = (HR + 7) / 8;
+    int bytes = 2 * NPA * 1024 + 4 * 64 * 128 + 1024;
+    if (bytes < BM * 64 * 4) bytes = BM * 64 * 4;                 // the tile epilogue parks the fp32 tile there
+    MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
+    static int configured = 0;
+    if (configured < bytes) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = bytes;
+    }
+    dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / 64)));
+    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW>), grid, dim3(512), bytes, s, d);
+    return 0;
+}
+// 0: not eligible, else the pixel tile (128 or 256)
+static int halo_tile(const mdm_gemm_desc& d, int min_tiles) {
+    if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 &&
+          d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW && (d.OW == 16 || d.OW == 32 || d.OW == 64) &&
+          d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && !d.out_f32))
+        return 0;
+    for (int bm : {256, 128}) {
+        if (bm % d.OW || d.OH % (bm / d.OW) || d.M % bm) continue;
+        const int R = bm / d.OW, NPA = ((R + 2) * (d.OW + 2) + 7) / 8;
+        if (NPA > 48) continue;
+        if ((int64_t)(d.M / bm) * (d.N / 64) >= min_tiles) return bm;
+    }
+    return 0;
+}
+
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
@@ -1729,6 +1896,7 @@ static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES");
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
+static int g_halo = []() { const char* e = getenv("MDM_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_wgrad_lin = []() { const char* e = getenv("MDM_WGRAD_LIN"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
 
@@ -1824,7 +1992,12 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
         int rc;
         const int64_t t_mid = (int64_t)cdiv(d.M, 64) * cdiv(d.N, 128) * grid.z;
         const bool lin2 = g_lin2 && d.C0 <= 4096 && d.C1 <= 4096;     // a segment walks <= 8 KiB inside the zero page
-        if (big) {
+        const int hb = (g_halo && d.splitk <= 1) ? halo_tile(d, g_big_min_tiles) : 0;
+        if (hb) {
+            const int npw = (((hb / d.OW + 2) * (d.OW + 2) + 7) / 8 + 7) / 8;      // halo pieces per wave
+            rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4>(d, s) : launch_halo<256, 6>(d, s))
+                           : (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s));
+        } else if (big) {
             rc = !lin2 ? launch_lin<128, 128, 3, 8>(d, grid, s)
                  : g_lin2 == 2 ? launch_lin2<128, 128, 3, 2, 2, 2>(d, grid, s)
                  : g_lin2 == 4 ? launch_lin2<128, 128, 4, 4, 2, 1, true, true>(d, grid, s)

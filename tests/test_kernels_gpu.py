@@ -161,6 +161,44 @@ def test_conv_epilogue_rowvec_resid_accumulate(dt):
     assert _relerr(dst, _nhwc(want)) < _tol(dt, 1.5)
 
 
+@pytest.mark.parametrize("case", [(32, 32, 128, 0, 128), (32, 16, 64, 64, 256), (8, 64, 64, 0, 64)])
+def test_conv_halo_forward_and_data_gradient(case):
+    """3x3 stride-1 convolutions on maps large enough for the halo-staged kernel (whole image rows x 64 output
+    channels per workgroup; 256- and 128-pixel tiles; two concatenated sources): forward with the full epilogue,
+    data gradient through the per-tap transposed filters with accumulation into split destinations."""
+    from mdm import ops
+    dt = "bf16"
+    N, H, C0, C1, Cout = case
+    C = C0 + C1
+    g = torch.Generator().manual_seed(N + H + C)
+    x = _q(torch.randn(N, C, H, H, generator=g), dt)
+    w = _q(torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5), dt)
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(N, Cout, generator=g)
+    res = _q(torch.randn(N, Cout, H, H, generator=g), dt)
+    y = F.conv2d(x, w, b, padding=1) + rv[:, :, None, None] + res
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout)
+    xh = _nhwc(x)
+    s0 = _up(xh[..., :C0].contiguous(), dt)
+    s1 = _up(xh[..., C0:].contiguous(), dt) if C1 else None
+    out = torch.empty(N, H, H, Cout, device=_dev(), dtype=torch.bfloat16)
+    ops.conv_fwd(1, geom, s0, s1, _up(_w_tap(w), dt), b.to(_dev()), out, rowvec=rv.to(_dev()), rv_ld=Cout, resid=_up(_nhwc(res), dt))
+    torch.cuda.synchronize()
+    assert _relerr(out, _nhwc(y)) < _tol(dt)
+    gy = _q(torch.randn(N, Cout, H, H, generator=g), dt)
+    base = _q(torch.randn(N, C, H, H, generator=g), dt)
+    want = _nhwc(base + F.conv_transpose2d(gy, w, padding=1))
+    bh = _nhwc(base)
+    d0 = _up(bh[..., :C0].contiguous(), dt)
+    d1 = _up(bh[..., C0:].contiguous(), dt) if C1 else None
+    wT = _up(_w_tap(w).transpose(1, 2).contiguous(), dt)
+    ops.conv_dgrad_t(1, geom, _up(_nhwc(gy), dt), wT, d0, 1, d1, 1)
+    torch.cuda.synchronize()
+    assert _relerr(d0, want[..., :C0]) < _tol(dt, 1.5)
+    if C1:
+        assert _relerr(d1, want[..., C0:]) < _tol(dt, 1.5)
+
+
 def test_conv_tap_split_with_epilogue():
     """Small-M 3x3 conv: reduction split over the filter taps (slabs + epilogue kernel), full epilogue."""
     from mdm import ops
