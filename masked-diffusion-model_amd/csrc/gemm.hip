@@ -1611,6 +1611,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     constexpr int BN = 64, NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, NSB = 4;
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
+    MDM_T(const unsigned long long t_entry = stamp_now();)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave / WC, wc = wave % WC;
@@ -1653,6 +1654,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         lds_dma16((cs < NCS && !(d._p0 & 2)) ? b_row + off : zlane, bring + stage * B_BYTES + wave * 1024);
     };
 
+    // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..2 (in flight while the offset tables below are built)
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) issue_a(k, 0, lds);
+    issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
+
     // ---- per-lane fragment offsets
     int a_addr[9][MI];
 #pragma unroll
@@ -1682,11 +1688,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..2
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) issue_a(k, 0, lds);
-    issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
-
     int a_cur = 0;                         // byte offset of the halo buffer being multiplied
     int b_stage = 0;                       // ring stage of the current tap-slab
 #define MDM_HALO_A(tau) ((((tau) + 9) % 9) < NPW ? 1 : 0)
@@ -1699,18 +1700,30 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         if ((T) < NPW) issue_a((T), cs + 1, lds + (a_cur ^ a_flip));                                             \
         const char* As = lds + a_cur;                                                                            \
         const char* Bs = bring + b_stage * B_BYTES;                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
-            bf16x8 af[MI], bfr[NI];                                                                              \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
-                af[i] = *reinterpret_cast<const bf16x8*>(As + (a_addr[T][i] ^ (ks << 6)));                       \
+        bf16x8 bfr[2][NI];                                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
-                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + b_off[ks][j]);                                    \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
-                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);      \
+                bfr[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + b_off[ks][j]);                                \
+        if ((T) == 0) {            /* a new halo buffer: its fragments can only be read behind this barrier */   \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+                    afr[0][ks][i] = *reinterpret_cast<const bf16x8*>(As + (a_addr[0][i] ^ (ks << 6)));           \
         }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], afr[(T) & 1][0][i], acc[i][j], 0, 0, 0); \
+        if ((T) < 8) {             /* the next tap reads the SAME halo buffer at shifted rows: fetch it now */    \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+                    afr[((T) + 1) & 1][ks][i] = *reinterpret_cast<const bf16x8*>(As + (a_addr[((T) + 1) % 9][i] ^ (ks << 6))); \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], afr[(T) & 1][1][i], acc[i][j], 0, 0, 0); \
         b_stage = (b_stage + 1) & 3;                                                                             \
     }
+    bf16x8 afr[2][2][MI];                  // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
+    MDM_T(const unsigned long long tstart = stamp_now();)
     const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
     for (int cs = 0; cs < NCS; ++cs) {
         MDM_HALO_TAP(0) MDM_HALO_TAP(1) MDM_HALO_TAP(2) MDM_HALO_TAP(3) MDM_HALO_TAP(4)
@@ -1720,9 +1733,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #undef MDM_HALO_TAP
 #undef MDM_HALO_A
     wait_vmcnt<0>();
+    MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
-    if (m0 < d.M) { /* uniform */ }
     epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+#ifdef MDM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const unsigned widx = blockIdx.x * NW + wave;
+        if (widx < 4096) {
+            unsigned long long* r = g_stamp_buf + widx * 32;
+            r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = NCS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
+            r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
+        }
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------
