@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
                                                      float* stats) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
-    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
                                                      float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
-    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
                                                          float* stats, float* ws) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
-    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
                                                          float* ws) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
-    const int img = blockIdx.y, cb = blockIdx.x * CBLK;
+    const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
     const bool on = t < VB * PL && c < C;
@@ -737,14 +737,16 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
 
 // channels per workgroup: whole groups, whole 16-byte vectors, at least 32 channels
 static int g_gn_regs = []() { const char* e = getenv("MDM_GN_REGS"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_gn_minc = []() { const char* e = getenv("MDM_GN_MINC"); return e ? atoi(e) : 32; }();
+static int g_gn_minc = []() { const char* e = getenv("MDM_GN_MINC"); return e ? atoi(e) : 0; }();   // 0: by map size
 // pixel-chunked statistics + apply launches: measured no faster than the single launch at cfg2 (13.4 vs 13.7 us
 // forward, 25.3 vs 24.1 us backward on 32x32x128: two ~5 us launch floors eat the bandwidth gain) -> opt-in
 static int g_gn_split = []() { const char* e = getenv("MDM_GN_SPLIT"); return (e && e[0] == '1') ? 1 : 0; }();
 static int gn_cblk(int C, int G, int N, int P) {
     int cpg = C / G, l = cpg;
     while (l % 8) l += cpg;            // lcm(cpg, 8)
-    int want = g_gn_minc;             // (16 measured slower: 8.78 vs 7.84 ms/step at cfg2)
+    // 32 channels per workgroup; 16 on large maps (more workgroups pulling HBM: 12.3 -> 10.1 us forward,
+    // 21.0 -> 15.8 us backward on 32x32x128; slower on the small maps, where the launch floor dominates)
+    int want = g_gn_minc > 0 ? g_gn_minc : (P > 256 ? 16 : 32);
     int cb = l;
     while (cb < want) cb += l;
     return cb > C ? C : cb;
@@ -755,7 +757,7 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
-    dim3 grid(cdiv(C, cblk), N);
+    dim3 grid(N, cdiv(C, cblk));
     const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane
     const int chunks = cdiv(np, 4);
     if (dtype == MDM_BF16 && g_gn_regs && g_gn_split && ws && np > 4 && chunks <= 32 && (int64_t)grid.x * grid.y < 512) {
@@ -800,7 +802,7 @@ extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     MDM_REQUIRE(!(sum_img || sum_all) || (acc0 == 0 && C1 == 0), "groupnorm_bwd_sums: column sums need a plain (non-accumulating, single-source) dx");
-    dim3 grid(cdiv(C, cblk), N);
+    dim3 grid(N, cdiv(C, cblk));
     const int np = cdiv(P, 256 / (cblk / 8));
     const int chunks = cdiv(np, 4);
     if (dtype == MDM_BF16 && g_gn_regs && g_gn_split && ws && np > 4 && chunks <= 32 && (int64_t)grid.x * grid.y < 512) {
