@@ -287,53 +287,69 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(mdm_gemm_desc d) {
 // ----------------------------------------------------------------------------
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(mdm_gemm_desc d) {
-    constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
-    __shared__ __attribute__((aligned(16))) float As[BK * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+    // BK: granule of the split-K chunks (host rule); KS: k per loop trip = 4 granules, so that four 16-byte
+    // loads per operand are in flight per thread, and the next trip's loads are issued before this trip's
+    // FMAs (the first version did load -> barrier -> store -> barrier -> FMA per 16 k: one full memory
+    // latency per granule, 28 us for the [32,512]x[4992,512] time-embedding projection).
+    constexpr int BM = 64, BN = 64, BK = 16, KS = 64, NQ = KS / BK, LD = 68;
+    __shared__ __attribute__((aligned(16))) float As[KS * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[KS * LD];
     const int t = threadIdx.x;
     const int tiles_n = (d.N + BN - 1) / BN;
     const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
     const ZInfo z = decode_z(d, BK);
 
-    const int rr = t >> 2, rk = (t & 3) * 4;     // row-operand mapping: 64 rows x 4 vectors
-    const int ck = t >> 4, cc = (t & 15) * 4;    // col-operand mapping: 16 k-rows x 16 vectors
+    const int rr = t >> 2, rk = (t & 3) * 4;     // row-operand mapping: 64 rows x 4 vectors (per granule)
+    const int ck = t >> 4, cc = (t & 15) * 4;    // col-operand mapping: 16 k-rows x 16 vectors (per granule)
     RowPix arow = {0, 0, 0};
     if (LAYOUT != 2 && d.conv && m0 + rr < d.M) arow = decode_row(d, m0 + rr);
 
     float acc[4][4] = {};
     const int ty = t >> 4, tx = t & 15;
-    for (int k0 = z.kbeg; k0 < z.kend; k0 += BK) {
-        float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
-        if (LAYOUT != 2) {
-            const float* p = a_row_ptr<float>(d, z, m0 + rr, arow, k0 + rk);
-            if (p) av = load4(p);
-        } else {
-            const float* p = a_col_ptr<float>(d, z, k0 + ck, m0 + cc);
-            if (p) av = load4(p);
+    float4 av[NQ], bv[NQ];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            av[q] = make_float4(0, 0, 0, 0); bv[q] = make_float4(0, 0, 0, 0);
+            const int kq = k0 + q * BK;
+            if (LAYOUT != 2) {
+                const float* p = a_row_ptr<float>(d, z, m0 + rr, arow, kq + rk);
+                if (p) av[q] = load4(p);
+            } else {
+                const float* p = a_col_ptr<float>(d, z, kq + ck, m0 + cc);
+                if (p) av[q] = load4(p);
+            }
+            if (LAYOUT == 0) {
+                const float* p = b_row_ptr<float>(d, z, n0 + rr, kq + rk);
+                if (p) bv[q] = load4(p);
+            } else {
+                const float* p = b_col_ptr<float>(d, z, kq + ck, n0 + cc);
+                if (p) bv[q] = load4(p);
+            }
         }
-        if (LAYOUT == 0) {
-            const float* p = b_row_ptr<float>(d, z, n0 + rr, k0 + rk);
-            if (p) bv = load4(p);
-        } else {
-            const float* p = b_col_ptr<float>(d, z, k0 + ck, n0 + cc);
-            if (p) bv = load4(p);
-        }
-        __syncthreads();
-        if (LAYOUT != 2) {
-            As[(rk + 0) * LD + rr] = av.x; As[(rk + 1) * LD + rr] = av.y;
-            As[(rk + 2) * LD + rr] = av.z; As[(rk + 3) * LD + rr] = av.w;
-        } else {
-            *reinterpret_cast<float4*>(&As[ck * LD + cc]) = av;
-        }
-        if (LAYOUT == 0) {
-            Bs[(rk + 0) * LD + rr] = bv.x; Bs[(rk + 1) * LD + rr] = bv.y;
-            Bs[(rk + 2) * LD + rr] = bv.z; Bs[(rk + 3) * LD + rr] = bv.w;
-        } else {
-            *reinterpret_cast<float4*>(&Bs[ck * LD + cc]) = bv;
-        }
+    };
+    fetch(z.kbeg);
+    for (int k0 = z.kbeg; k0 < z.kend; k0 += KS) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < BK; ++k) {
+        for (int q = 0; q < NQ; ++q) {
+            if (LAYOUT != 2) {
+                As[(q * BK + rk + 0) * LD + rr] = av[q].x; As[(q * BK + rk + 1) * LD + rr] = av[q].y;
+                As[(q * BK + rk + 2) * LD + rr] = av[q].z; As[(q * BK + rk + 3) * LD + rr] = av[q].w;
+            } else {
+                *reinterpret_cast<float4*>(&As[(q * BK + ck) * LD + cc]) = av[q];
+            }
+            if (LAYOUT == 0) {
+                Bs[(q * BK + rk + 0) * LD + rr] = bv[q].x; Bs[(q * BK + rk + 1) * LD + rr] = bv[q].y;
+                Bs[(q * BK + rk + 2) * LD + rr] = bv[q].z; Bs[(q * BK + rk + 3) * LD + rr] = bv[q].w;
+            } else {
+                *reinterpret_cast<float4*>(&Bs[(q * BK + ck) * LD + cc]) = bv[q];
+            }
+        }
+        __syncthreads();
+        if (k0 + KS < z.kend) fetch(k0 + KS);          // in flight under the FMAs below
+#pragma unroll 16
+        for (int k = 0; k < KS; ++k) {
             float4 a = *reinterpret_cast<const float4*>(&As[k * LD + ty * 4]);
             float4 b = *reinterpret_cast<const float4*>(&Bs[k * LD + tx * 4]);
             float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
@@ -350,6 +366,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(mdm_gemm_desc d) {
             int m = m0 + ty * 4 + i;
             if (m < d.M) epilogue4<float>(d, z, m, n, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
         }
+    }
+}
+
+
+// ----------------------------------------------------------------------------
+// Skinny fp32 linear layer D[m][n] = alpha * sum_k A[m][k] B[n][k] + bias[n] with M <= 32 rows (the batch):
+// the time-embedding MLP and the per-block projections (unet6.py:395-399, 350).  A 64x64-tiled kernel gives
+// 8 workgroups for a [32,512]x[512,512] layer, each pulling 128 KB of weights alone (36 us, and three such
+// layers sit in a row at the very start of the forward).  Here a workgroup owns 16 output columns: the
+// activation matrix (<= 64 KB) is parked in LDS once, thread (column, k-part) streams its share of the weight
+// row in 16-byte pieces, 256 B contiguous per 16 lanes, the 16 k-parts meet in LDS at the end.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_skinny_f32_kernel(mdm_gemm_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // A [32][K] then the partials [32][16][17]
+    const int t = threadIdx.x, kp = t & 15, nl = t >> 4;
+    const int n0 = blockIdx.x * 16, K = d.K, M = d.M;
+    const float* A = reinterpret_cast<const float*>(d.A);
+    for (int i = t * 4; i < 32 * K; i += 1024) {
+        const int m = i / K, k = i - m * K;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M) v = *reinterpret_cast<const float4*>(A + (int64_t)m * d.lda + k);
+        *reinterpret_cast<float4*>(sm + i) = v;
+    }
+    __syncthreads();
+    float acc[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) acc[m] = 0.f;
+    const int n = n0 + nl;
+    const float* Brow = reinterpret_cast<const float*>(d.B) + (int64_t)(n < d.N ? n : 0) * d.ldb;
+    for (int k = kp * 4; k < K; k += 64) {
+        const float4 b = n < d.N ? *reinterpret_cast<const float4*>(Brow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const float4 a = *reinterpret_cast<const float4*>(sm + m * K + k);
+            acc[m] = fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, acc[m]))));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 32; ++m) sm[(m * 16 + nl) * 17 + kp] = acc[m];
+    __syncthreads();
+    for (int o = t; o < 32 * 16; o += 256) {
+        const int m = o >> 4, c = o & 15;
+        if (m >= M || n0 + c >= d.N) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += sm[o * 17 + q];
+        v *= d.alpha;
+        if (d.bias) v += d.bias[n0 + c];
+        reinterpret_cast<float*>(d.D0)[(int64_t)m * d.ldd0 + n0 + c] = v;
     }
 }
 
@@ -2003,7 +2069,17 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
     MDM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
     dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * d.splitk));
     MDM_REQUIRE(grid.z <= 65535, "gemm: grid.z=%u too large", grid.z);
-    if (d.dtype == MDM_F32) {
+    if (d.dtype == MDM_F32 && d.layout == 0 && !d.conv && d.M <= 32 && d.K % 64 == 0 && d.K <= 512 && d.splitk <= 1 &&
+        d.batch == 1 && !d.rowvec && !d.resid && !d.acc0 && d.N0 == d.N && d.lda % 4 == 0 && d.ldb % 4 == 0) {
+        static bool configured = false;
+        const int bytes = 32 * (d.K > 16 * 17 ? d.K : 16 * 17) * 4;
+        if (!configured) {
+            MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_skinny_f32_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 512 * 4));
+            configured = true;
+        }
+        hipLaunchKernelGGL(linear_skinny_f32_kernel, dim3((unsigned)cdiv(d.N, 16)), dim3(256), bytes, s, d);
+    } else if (d.dtype == MDM_F32) {
         switch (d.layout) {
             case 0: hipLaunchKernelGGL((gemm_f32_kernel<0>), grid, dim3(256), 0, s, d); break;
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;

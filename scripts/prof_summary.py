@@ -2,10 +2,12 @@
 """Per-category summary of a rocprofv3 kernel_stats.csv: python scripts/prof_summary.py stats.csv <steps profiled>"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1]))); steps = float(sys.argv[2])
-cats = collections.OrderedDict((k, [0, 0.0]) for k in ("wgrad ring<.,.,2", "conv_lin", "gemm_ring other", "gemm_bf16", "gemm_f32", "splitk_reduce", "splitk_epilogue", "gn_bwd", "gn_fwd", "softmax", "adamw/sqnorm/transpose", "other"))
+cats = collections.OrderedDict((k, [0, 0.0]) for k in ("wgrad_lin", "conv_halo", "wgrad ring<.,.,2", "conv_lin", "gemm_ring other", "gemm_bf16", "gemm_f32", "splitk_reduce", "splitk_epilogue", "gn_bwd", "gn_fwd", "softmax", "adamw/sqnorm/transpose", "other"))
 def cat(n):
     if "gemm_ring_kernel" in n: return "wgrad ring<.,.,2" if ", 2, " in n.split("(")[0] else "gemm_ring other"
     if "conv_lin" in n: return "conv_lin"
+    if "wgrad_lin" in n: return "wgrad_lin"
+    if "conv_halo" in n: return "conv_halo"
     for k in ("gemm_bf16", "gemm_f32", "splitk_reduce", "splitk_epilogue", "gn_bwd", "gn_fwd", "softmax"):
         if k in n: return k
     if any(k in n for k in ("adamw", "sqnorm", "transpose_shadow")): return "adamw/sqnorm/transpose"
@@ -16,5 +18,5 @@ for r in rows:
 print(f"kernels/step {nk/steps:.0f}, kernel time/step {tot/steps/1e6:.3f} ms")
 for k, (n, t) in cats.items():
     print(f"  {k:26s} {n/steps:6.1f} launches/step  {t/steps/1e6:7.3f} ms/step  avg {t/max(n,1)/1e3:6.1f} us")
-for r in rows[:14]:
+for r in rows[:18]:
     print(f"    {r['Name'][:84]:84s} {int(r['Calls'])/steps:6.1f}  {float(r['TotalDurationNs'])/steps/1e6:6.3f} ms  {float(r['AverageNs'])/1e3:6.1f} us")

@@ -229,6 +229,21 @@ def test_conv_tap_split_with_epilogue():
     assert _relerr(dst, _nhwc(want)) < _tol(dt, 1.5)
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 512, 128), (32, 4992, 512), (5, 80, 64)])
+def test_skinny_fp32_linear(M, N, K):
+    """The batch-sized fp32 linear layers of the time-embedding path (unet6.py:395-399, 350) take a dedicated kernel."""
+    from mdm import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    want = 0.5 * (a @ w.t()) + b
+    D = torch.full((M, N), float("nan"), device=_dev())
+    ops.matmul(0, 0, M, N, K, a.to(_dev()), K, w.to(_dev()), K, D, N, alpha=0.5, bias=b.to(_dev()))
+    torch.cuda.synchronize()
+    assert _relerr(D, want) < 1e-5
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(3, 64, 64, 256), (2, 16, 16, 64), (2, 256, 256, 64), (1, 40, 72, 136)])
 def test_batched_matmul_layouts(dt, shape):
