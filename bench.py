@@ -13,8 +13,9 @@ optimisation step (degrade -> shift -> U-Net fwd -> loss -> U-Net bwd -> [all-re
 on a batch that is already resident in HBM.  One JSON line on stdout (rank 0).
 
 Extra objects in that line:
-  roofline     the contraction kernel family (every `mdm_gemm` launch of the step -- `conv_lin_kernel` /
-               `gemm_ring_kernel`: conv fwd/dgrad/wgrad, 1x1 convs, attention products): algorithmic FLOPs of those launches / their HIP-event
+  roofline     the contraction kernel family (every `mdm_gemm` launch of the step -- `conv_halo_kernel` / `conv_lin2_kernel` /
+               `wgrad_lin_kernel` / `gemm_ring_kernel`: conv fwd/dgrad/wgrad, 1x1 convs, attention products --
+               and the batched split-K sum of the weight gradients): algorithmic FLOPs of those launches / their HIP-event
                time, against the dense bf16 MFMA peak;
   step_hbm     north_star's whole-step figure: algorithmic bytes (SURVEY 8(d) counting rule) /
                (step time x 8 TB/s);
@@ -183,7 +184,9 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         with _lib.Recording() as front:
             step._emit_device_front()
-        pick = lambda rec: (lambda i, name: name == "mdm_gemm" and rec.flops.get(i, (0, -1))[1] == dt)
+        # the family = every bf16 mdm_gemm call plus the batched split-K sum that finishes the weight gradients
+        pick = lambda rec: (lambda i, name: (name == "mdm_gemm" and rec.flops.get(i, (0, -1))[1] == dt) or
+                            name == "mdm_splitk_reduce_pending")
         tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
         reps = 3
         for _ in range(reps):
@@ -192,13 +195,14 @@ def main():
             for rec in (front, model.backward_plan):
                 for i, ms in rec.run_timed(st, pick(rec)):
                     tot_ms += ms
-                    tot_fl += rec.flops[i][0]
-                    n_launch += 1
+                    if i in rec.flops:
+                        tot_fl += rec.flops[i][0]
+                        n_launch += 1
             optim.emit_update(ema.shadow, 1.0, 1.0 / world)
         torch.cuda.synchronize()
         log("event-timed replay done")
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        name = ("mdm_gemm bf16 family: conv_lin_kernel / gemm_ring_kernel (+ splitk reduce/epilogue)" if dt == mdm.BF16
+        name = ("mdm_gemm bf16 family: conv_halo / conv_lin2 / wgrad_lin / gemm_ring kernels (+ split-K epilogue and batched reduce)" if dt == mdm.BF16
                 else "gemm_f32_kernel")
         peak = PEAK_BF16_TFLOPS if dt == mdm.BF16 else 157.3
         # HBM bytes per launch of this kernel family from PMC counters: collected out of band by
