@@ -99,13 +99,20 @@ typedef struct mdm_gemm_desc {
      * library and summed by the next mdm_splitk_reduce_pending() -- ONE launch for every queued contraction
      * (the weight gradients of a whole backward chunk) instead of one ~5 us launch each.  ws must stay
      * untouched until then (give every deferred call its own slice). */
-    int32_t defer_reduce; int32_t _p2;
+    int32_t defer_reduce;
+    /* weight gradients on the linear-gather kernel only, with defer_reduce: 1 = queue this contraction instead of
+     * launching it; it shares ONE launch with the next such contraction (the conv2 / conv1 pair of a residual
+     * block), or is launched by mdm_gemm_flush() / mdm_splitk_reduce_pending().  Its operands must stay
+     * untouched until then. */
+    int32_t defer_launch;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
 /* Sums every queued split-K partial (see defer_reduce) into its destination and empties the queue.
  * The queue is per host thread; queue and launch must be recorded/captured in the same order they are replayed. */
 int mdm_splitk_reduce_pending(void* stream);
+/* Launches every queued (defer_launch) contraction. */
+int mdm_gemm_flush(void* stream);
 /* What mdm_gemm would choose for this descriptor given unlimited workspace: the split count and the
  * workspace bytes it needs (0 when it would not use partial slabs).  No launch. */
 int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out);

@@ -105,7 +105,7 @@ __device__ __forceinline__ const T* gather_ptr(const mdm_gemm_desc& d, const Row
     return reinterpret_cast<const T*>(d.src1) + spix * d.ld1 + (c - d.C0);
 }
 
-struct ZInfo { int batch, tap, kbeg, kend, ks, outer; };
+struct ZInfo { int batch, tap, kbeg, kend, ks, outer, nouter; };   // nouter: taps / batches the split-K partial slabs are laid out over
 
 // Workgroups are dealt to the 8 XCDs round-robin by linear id; each XCD has its own L2.  This bijection hands
 // XCD x the x-th CONTIGUOUS eighth of the work items instead, so items that read the same operand slices
@@ -122,7 +122,7 @@ __device__ __forceinline__ ZInfo decode_z(const mdm_gemm_desc& d, int BK) {
     int zi = blockIdx.z;
     int sk = d.splitk < 1 ? 1 : d.splitk;
     int outer = zi / sk, ks = zi - outer * sk;
-    z.ks = ks; z.outer = outer;
+    z.ks = ks; z.outer = outer; z.nouter = gridDim.z / sk;
     if (d.layout == 2 && d.conv) z.tap = outer; else z.batch = d.conv ? 0 : outer;
     if (sk > 1) {
         int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
@@ -157,8 +157,7 @@ __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z
     else          { base = d.D1; ld = d.ldd1; col = n - d.N0; acc = d.acc1; }
     int64_t off = z.batch * d.sD + z.tap * d.dtap + (int64_t)m * ld + col;
     if (d.splitk > 1 && d.ws) {          // partial slab [split][tap|batch][M][N], plain stores; summed by splitk_reduce_kernel
-        const int nouter = gridDim.z / d.splitk;
-        float* p = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * nouter + z.outer) * ((int64_t)d.M * d.N) + (int64_t)m * d.N + n;
+        float* p = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * z.nouter + z.outer) * ((int64_t)d.M * d.N) + (int64_t)m * d.N + n;
         store4(p, v);
     } else if (d.splitk > 1) {
         float* p = reinterpret_cast<float*>(base) + off;
@@ -267,7 +266,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(mdm_gemm_desc d) {
     const int n4 = d.N / 4;
     const int64_t total4 = (int64_t)d.M * n4;
-    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.ks = 0; z.outer = 0;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.ks = 0; z.outer = 0; z.nouter = 1;
     mdm_gemm_desc e = d;
     e.splitk = 1;                       // epilogue4 must take its plain-store branch
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -988,7 +987,7 @@ __global__ __launch_bounds__(64 * NW) void conv_lin_kernel(mdm_gemm_desc d) {
     const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     const int sk = d.splitk < 1 ? 1 : d.splitk;
-    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.ks = blockIdx.z;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.nouter = 1; z.ks = blockIdx.z;
 
     const int r_sub = lane >> 3, r_lch = (lane & 7) ^ r_sub;
     const int sgn = d.transposed ? -1 : 1;
@@ -1206,7 +1205,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int sk = d.splitk < 1 ? 1 : d.splitk;
-    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.ks = blockIdx.z;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.nouter = 1; z.ks = blockIdx.z;
 
     const int r_sub = lane >> 3, r_lch = (lane & 7) ^ r_sub;
     const int sgn = d.transposed ? -1 : 1;
@@ -1489,7 +1488,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
 // Requires: stride 1, no upsample, IH == OH, IW == OW, 64 % OW == 0, OH a power of two, K % 64 == 0.
 // ----------------------------------------------------------------------------
 template <int BM, int BN, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
+__device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item, const int tiles_x) {
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;
@@ -1504,12 +1503,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (d.N + BN - 1) / BN;
     // work item order: k-range major, then filter tap, then output tile -- a contiguous run per XCD (xcd_remap)
-    const int sk = d.splitk < 1 ? 1 : d.splitk, ntap = d.KH * d.KW, per_k = ntap * (int)gridDim.x;
-    int item = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.z;
+    const int sk = d.splitk < 1 ? 1 : d.splitk, ntap = d.KH * d.KW, per_k = ntap * tiles_x;
     if (d._p0 & 8) item = xcd_remap(item, per_k * sk);        // measured: no gain at cfg2 (L2 hit rate is not the limiter)
-    const int ks_i = item / per_k, rem_i = item - ks_i * per_k, tap_i = rem_i / (int)gridDim.x, tile_i = rem_i - tap_i * (int)gridDim.x;
+    const int ks_i = item / per_k, rem_i = item - ks_i * per_k, tap_i = rem_i / tiles_x, tile_i = rem_i - tap_i * tiles_x;
     const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
-    ZInfo z; z.batch = 0; z.tap = tap_i; z.outer = tap_i; z.ks = ks_i; z.kbeg = 0; z.kend = d.K;
+    ZInfo z; z.batch = 0; z.tap = tap_i; z.outer = tap_i; z.nouter = ntap; z.ks = ks_i; z.kbeg = 0; z.kend = d.K;
     if (sk > 1) {
         const int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
         z.kbeg = ks_i * chunk; z.kend = min(d.K, z.kbeg + chunk);
@@ -1645,7 +1643,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-        const unsigned widx = (blockIdx.z * gridDim.x + blockIdx.x) * NW + wave;
+        const unsigned widx = (unsigned)blockIdx.x * NW + wave;
         if (widx < 4096) {
             unsigned long long* r = g_stamp_buf + widx * 32;
             r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = nk > 0 ? nk : 0; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
@@ -1655,6 +1653,19 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d) {
 #endif
 }
 
+
+// One launch = one or two weight gradients (flat 1-D grid of work items).  Two: the conv2 / conv1 pair of a
+// residual block -- independent leaves of the backward, the same kernel, so the pair shares one launch gap
+// and the tail of the first overlaps the head of the second (mdm_gemm: defer_launch).
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d, int tiles_x) {
+    wgrad_lin_body<BM, BN, NSTAGE, NW>(d, (int)blockIdx.x, tiles_x);
+}
+template <int BM, int BN, int NSTAGE, int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad_lin_pair_kernel(mdm_gemm_desc d0, int tiles_x0, int items0, mdm_gemm_desc d1, int tiles_x1) {
+    if ((int)blockIdx.x < items0) wgrad_lin_body<BM, BN, NSTAGE, NW>(d0, (int)blockIdx.x, tiles_x0);
+    else wgrad_lin_body<BM, BN, NSTAGE, NW>(d1, (int)blockIdx.x - items0, tiles_x1);
+}
 
 // ----------------------------------------------------------------------------
 // conv_halo: 3x3 stride-1 "same" convolution (forward, and the data gradient through the transposed shadow)
@@ -1908,16 +1919,40 @@ static int launch_lin2(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     return 0;
 }
 
+struct PendingWgrad { mdm_gemm_desc d; int tiles_x, items; bool big; };
+static thread_local std::vector<PendingWgrad> g_pending_wgrad;
+
 template <int BM, int BN, int NSTAGE, int NW>
-static int launch_wgrad_lin(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+static int launch_wgrad_lin(const PendingWgrad* a, const PendingWgrad* b, hipStream_t s) {
     constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
     static bool configured = false;
     if (!configured) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lin_kernel<BM, BN, NSTAGE, NW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lin_pair_kernel<BM, BN, NSTAGE, NW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((wgrad_lin_kernel<BM, BN, NSTAGE, NW>), grid, dim3(64 * NW), bytes, s, d);
+    if (b)
+        hipLaunchKernelGGL((wgrad_lin_pair_kernel<BM, BN, NSTAGE, NW>), dim3((unsigned)(a->items + b->items)), dim3(64 * NW), bytes, s,
+                           a->d, a->tiles_x, a->items, b->d, b->tiles_x);
+    else
+        hipLaunchKernelGGL((wgrad_lin_kernel<BM, BN, NSTAGE, NW>), dim3((unsigned)a->items), dim3(64 * NW), bytes, s, a->d, a->tiles_x);
+    return 0;
+}
+static int launch_wgrad(const PendingWgrad* a, const PendingWgrad* b, hipStream_t s) {
+    return a->big ? launch_wgrad_lin<128, 128, 3, 8>(a, b, s) : launch_wgrad_lin<64, 64, 4, 8>(a, b, s);
+}
+// launches every queued weight gradient (pairs of the same tile variant share a launch)
+int flush_wgrad(hipStream_t s) {
+    size_t i = 0;
+    while (i < g_pending_wgrad.size()) {
+        const PendingWgrad* a = &g_pending_wgrad[i];
+        const PendingWgrad* b = (i + 1 < g_pending_wgrad.size() && g_pending_wgrad[i + 1].big == a->big) ? &g_pending_wgrad[i + 1] : nullptr;
+        if (int rc = launch_wgrad(a, b, s)) { g_pending_wgrad.clear(); return rc; }
+        i += b ? 2 : 1;
+    }
+    g_pending_wgrad.clear();
     return 0;
 }
 static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
@@ -1992,7 +2027,9 @@ static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e
 
 static thread_local std::vector<ReduceSeg> g_pending;
 
+int flush_wgrad(hipStream_t s);
 int reduce_pending(hipStream_t s) {
+    if (int rc = flush_wgrad(s)) return rc;      // the partials must exist before they are summed
     size_t i = 0;
     while (i < g_pending.size()) {
         ReduceTable tab;
@@ -2116,8 +2153,11 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
         }
         if (rc) return rc;
     } else if (g_use_ring && g_wgrad_lin && wgrad_lin_eligible(d)) {
-        int rc = big ? launch_wgrad_lin<128, 128, 3, 8>(d, grid, s) : launch_wgrad_lin<64, 64, 4, 8>(d, grid, s);
-        if (rc) return rc;
+        MDM_REQUIRE((int64_t)grid.x * grid.z < (1ll << 30), "gemm: grid too large");
+        g_pending_wgrad.push_back(PendingWgrad{d, (int)grid.x, (int)(grid.x * grid.z), big});
+        // defer_launch: wait for the next weight gradient (or any flush) and share its launch
+        if (!(d.defer_launch && d.splitk > 1 && d.ws && d.defer_reduce && g_pending_wgrad.size() < 2))
+            if (int rc = flush_wgrad(s)) return rc;
     } else if (g_use_ring && ring_eligible(d)) {
         int rc = big ? (g_big_waves == 16 ? launch_ring<128, 128, 3, 16>(d, grid, s) : g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
                                          : launch_ring<128, 128, 3>(d, grid, s))
@@ -2162,6 +2202,7 @@ extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
     return mdm::gemm_launch(desc_host, mdm::pick_stream(stream));
 }
 extern "C" int mdm_splitk_reduce_pending(void* stream) { return mdm::reduce_pending(mdm::pick_stream(stream)); }
+extern "C" int mdm_gemm_flush(void* stream) { return mdm::flush_wgrad(mdm::pick_stream(stream)); }
 extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
     if (!splitk_out || !ws_bytes_out) { mdm::set_error("gemm_plan: null output"); return -1; }
     return mdm::gemm_launch(desc_host, nullptr, splitk_out, ws_bytes_out);

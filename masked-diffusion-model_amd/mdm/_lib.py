@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("src0", vp), ("src1", vp), ("ld0", i32), ("ld1", i32), ("wtap", i64),
         ("D0", vp), ("D1", vp), ("ldd0", i32), ("ldd1", i32), ("N0", i32), ("out_f32", i32), ("alpha", f32),
         ("acc0", i32), ("acc1", i32), ("bias", vp), ("rowvec", vp), ("rv_ld", i32), ("rows_per_img", i32),
-        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp), ("defer_reduce", i32), ("_p2", i32),
+        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp), ("defer_reduce", i32), ("defer_launch", i32),
     ]
 
 
@@ -39,6 +39,7 @@ _PROTOS = {
     "mdm_device_count": ([], i32),
     "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "mdm_splitk_reduce_pending": ([vp], i32),
+    "mdm_gemm_flush": ([vp], i32),
     "mdm_gemm_plan": ([C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i64)], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),

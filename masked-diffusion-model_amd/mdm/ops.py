@@ -92,20 +92,22 @@ def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None
               ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
 
 
-def _wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer):
+def _wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer, defer_launch=False):
     return dict(dtype=dt, layout=2, M=g.Cout, N=g.Cin, K=g.N * g.OH * g.OW,
                 conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
                 pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
                 src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, A=dy, lda=g.Cout,
                 D0=dw, ldd0=g.Cin, N0=g.Cin, out_f32=1, acc0=1, splitk=splitk, dtap=g.Cout * g.Cin, _flops=conv_flops(g),
-                ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0), dbias=dbias, defer_reduce=int(bool(defer)))
+                ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0), dbias=dbias, defer_reduce=int(bool(defer)),
+                defer_launch=int(bool(defer_launch)))
 
 
-def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None, dbias=None, defer=False):
+def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None, dbias=None, defer=False, defer_launch=False):
     """dw[tap][Cout][Cin] (fp32) += sum_pixels dy x gathered input.  `ws`: fp32 split-K workspace tensor;
     `dbias` (bf16 path only): fp32 [Cout] that also receives += column sums of dy.  `defer`: leave the sum of
-    the split-K partials to the next splitk_reduce_pending() (ws must be this call's own slice)."""
-    _lib.gemm(**_wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer))
+    the split-K partials to the next splitk_reduce_pending() (ws must be this call's own slice).  `defer_launch`
+    (with defer): queue the contraction itself; it shares the launch of the next weight gradient."""
+    _lib.gemm(**_wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer, defer_launch))
 
 
 def conv_wgrad_ws_bytes(dt, g: ConvGeom):

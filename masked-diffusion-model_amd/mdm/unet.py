@@ -219,7 +219,7 @@ class _Conv:
         own = getattr(self, "wgrad_ws", None)
         ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"),
                        ws=own if own is not None else n.splitk_ws, dbias=st.g(self.name + ".bias") if fuse_bias else None,
-                       defer=own is not None)
+                       defer=own is not None, defer_launch=own is not None and getattr(self, "pair_wgrad", False))
         if fork:
             _lib.call("mdm_side_end", _lib.stream())
         if not s0.needs_grad:
@@ -596,6 +596,13 @@ class UNet:
         # parameters are declared in forward order, so after the backward of spec j every gradient
         # at or above spec j's first parameter is complete (mdm.dist.GradComm cuts buckets there).
         self.bwd_marks = []
+        # conv2 of a residual block queues its weight gradient; conv1's (two backward steps later, only norm2's
+        # backward in between, which touches neither operand) launches both in one kernel
+        if os.environ.get("MDM_PAIR_WGRAD", "1") != "0":
+            for i in range(2, len(self.specs)):
+                c2, nm, c1 = self.specs[i], self.specs[i - 1], self.specs[i - 2]
+                if isinstance(c2, _Conv) and isinstance(nm, _Norm) and getattr(nm, "producer", None) is c1 and c2.src0 is nm.out:
+                    c2.pair_wgrad = True
         for s in reversed(self.specs):
             s.bwd()
             self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
