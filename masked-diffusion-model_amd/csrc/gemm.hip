@@ -1693,7 +1693,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int OW = d.OW, OH = d.OH, HW2 = OW + 2;
-    const int R = BM / OW, HR = (R + 2) * HW2, NPA = (HR + 7) >> 3, ABUF = NPA * 1024;
+    // the tile is R image rows of one image, or (maps of <= BM pixels) IMGS whole images with one halo block each
+    const int IMGS = BM > OH * OW ? BM / (OH * OW) : 1, R = IMGS > 1 ? OH : BM / OW;
+    const int HRI = (R + 2) * HW2, HR = IMGS * HRI, NPA = (HR + 7) >> 3, ABUF = NPA * 1024;
     char* const bring = lds + 2 * ABUF;
     char* const dummy = bring + NSB * B_BYTES;
     const int tiles_n = d.N / BN;
@@ -1709,10 +1711,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
         const int hr = (wave + 8 * k) * 8 + (lane >> 3);
-        const int hy = hr / HW2, hx = hr - hy * HW2;
+        const int il = hr / HRI, hrem = hr - il * HRI;
+        const int hy = hrem / HW2, hx = hrem - hy * HW2;
         const int y = y0 - 1 + hy, x = hx - 1;
         const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M && !(d._p0 & 1);
-        apix[k] = ok ? (img * OH + y) * OW + x : -1;
+        apix[k] = ok ? ((img + il) * OH + y) * OW + x : -1;
     }
     auto issue_a = [&](int k, int cs, char* abuf) {                 // k compile-time after unrolling
         const int p = wave + 8 * k;
@@ -1741,8 +1744,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = wr * WM + i * 16 + (lane & 15);
-        const int r = ml / OW, x = ml - r * OW;
-        const int hb = (r + 1) * HW2 + x + 1;
+        const int il = ml / (R * OW), mrem = ml - il * (R * OW);
+        const int r = mrem / OW, x = mrem - r * OW;
+        const int hb = il * HRI + (r + 1) * HW2 + x + 1;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int ty = tp / 3, tx = tp - ty * 3;
@@ -1960,9 +1964,14 @@ static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
            d.OW > 0 && 64 % d.OW == 0 && (d.OH & (d.OH - 1)) == 0 && d.K % 64 == 0 && d.C0 % 8 == 0 && d.C1 % 8 == 0;
 }
 
+static int g_halo_small = []() { const char* e = getenv("MDM_HALO_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
+static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of one halo buffer
+    const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
+    return (imgs * (R + 2) * (OW + 2) + 7) / 8;
+}
 template <int BM, int NPW>
 static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
-    const int R = BM / d.OW, HR = (R + 2) * (d.OW + 2), NPA = (HR + 7) / 8;
+    const int NPA = halo_pieces(BM, d.OH, d.OW);
     int bytes = 2 * NPA * 1024 + 4 * 64 * 128 + 1024;
     if (bytes < BM * 64 * 4) bytes = BM * 64 * 4;                 // the tile epilogue parks the fp32 tile there
     MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
@@ -1976,18 +1985,26 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
     hipLaunchKernelGGL((conv_halo_kernel<BM, NPW>), grid, dim3(512), bytes, s, d);
     return 0;
 }
-// 0: not eligible, else the pixel tile (128 or 256)
+// 0: not eligible, else the pixel tile (64, 128 or 256)
 static int halo_tile(const mdm_gemm_desc& d, int min_tiles) {
     if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 &&
-          d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW && (d.OW == 16 || d.OW == 32 || d.OW == 64) &&
+          d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW &&
           d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && !d.out_f32))
         return 0;
-    for (int bm : {256, 128}) {
-        if (bm % d.OW || d.OH % (bm / d.OW) || d.M % bm) continue;
-        const int R = bm / d.OW, NPA = ((R + 2) * (d.OW + 2) + 7) / 8;
-        if (NPA > 48) continue;
-        if ((int64_t)(d.M / bm) * (d.N / 64) >= min_tiles) return bm;
+    if (d.OW == 16 || d.OW == 32 || d.OW == 64) {
+        for (int bm : {256, 128}) {
+            if (bm % d.OW || d.OH % (bm / d.OW) || d.M % bm) continue;
+            if (halo_pieces(bm, d.OH, d.OW) > 48) continue;
+            if ((int64_t)(d.M / bm) * (d.N / 64) >= min_tiles) return bm;
+        }
+        return 0;
     }
+    // small maps (4x4, 8x8): 64-pixel tiles of whole images.  Too few workgroups to fill the chip, but a workgroup's
+    // time is set by the filter bytes it streams (64 channels x 9 C: the same for every tile size), one launch
+    // replaces the tap-split conv + its epilogue launch, and the tile holds whole images (GroupNorm-fusable)
+    // (4x4 maps with > 256 input channels: 9 C x 64 filter bytes per workgroup outweigh the saved launch -- 17.1 vs 14.4 us)
+    if (g_halo_small && (d.OW == 4 || d.OW == 8) && d.OH == d.OW && 64 % (d.OH * d.OW) == 0 && d.M % 64 == 0 &&
+        !(d.OW == 4 && d.Ck > 256)) return 64;
     return 0;
 }
 
@@ -2078,7 +2095,9 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
         // small-M forward / data gradient: too few tiles to fill the chip -> split the filter taps over grid z
         d.splitk = 1;
         const int taps = d.KH * d.KW;
-        if (g_tap_split && d.ws && d.dtype == MDM_BF16 && ring_eligible(d) && taps >= 9 && taps % 3 == 0 && tiles <= 160) {
+        if (g_halo && halo_tile(d, g_big_min_tiles) == 64) {
+            /* single launch on the halo kernel: no tap split */
+        } else if (g_tap_split && d.ws && d.dtype == MDM_BF16 && ring_eligible(d) && taps >= 9 && taps % 3 == 0 && tiles <= 160) {
             int sk = tiles <= 48 ? taps : 3;
             if (taps % sk) sk = 3;
             if (d.ws_bytes >= (int64_t)sk * d.M * d.N * 4) d.splitk = sk;
@@ -2131,9 +2150,10 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
         const bool lin2 = g_lin2 && d.C0 <= 4096 && d.C1 <= 4096;     // a segment walks <= 8 KiB inside the zero page
         const int hb = (g_halo && d.splitk <= 1) ? halo_tile(d, g_big_min_tiles) : 0;
         if (hb) {
-            const int npw = (((hb / d.OW + 2) * (d.OW + 2) + 7) / 8 + 7) / 8;      // halo pieces per wave
+            const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
             rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4>(d, s) : launch_halo<256, 6>(d, s))
-                           : (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s));
+                 : hb == 128 ? (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s))
+                             : (npw <= 2 ? launch_halo<64, 2>(d, s) : launch_halo<64, 3>(d, s));
         } else if (big) {
             rc = !lin2 ? launch_lin<128, 128, 3, 8>(d, grid, s)
                  : g_lin2 == 2 ? launch_lin2<128, 128, 3, 2, 2, 2>(d, grid, s)

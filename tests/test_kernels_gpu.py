@@ -161,7 +161,9 @@ def test_conv_epilogue_rowvec_resid_accumulate(dt):
     assert _relerr(dst, _nhwc(want)) < _tol(dt, 1.5)
 
 
-@pytest.mark.parametrize("case", [(32, 32, 128, 0, 128), (32, 16, 64, 64, 256), (8, 64, 64, 0, 64)])
+@pytest.mark.parametrize("case", [(32, 32, 128, 0, 128), (32, 16, 64, 64, 256), (8, 64, 64, 0, 64),
+                                  # small maps: 64-pixel tiles of whole images (one 8x8 image / four 4x4 images per workgroup)
+                                  (8, 8, 128, 0, 128), (16, 4, 64, 64, 256)])
 def test_conv_halo_forward_and_data_gradient(case):
     """3x3 stride-1 convolutions on maps large enough for the halo-staged kernel (whole image rows x 64 output
     channels per workgroup; 256- and 128-pixel tiles; two concatenated sources): forward with the full epilogue,
@@ -203,24 +205,24 @@ def test_conv_tap_split_with_epilogue():
     """Small-M 3x3 conv: reduction split over the filter taps (slabs + epilogue kernel), full epilogue."""
     from mdm import ops
     dt = "bf16"
-    N, H, C, Cout = 8, 4, 64, 128
+    N, H, W, C, Cout = 8, 4, 8, 64, 128          # non-square map: not taken by the whole-image halo kernel
     g = torch.Generator().manual_seed(31)
-    x = _q(torch.randn(N, C, H, H, generator=g), dt)
+    x = _q(torch.randn(N, C, H, W, generator=g), dt)
     w = _q(torch.randn(Cout, C, 3, 3, generator=g) / 24.0, dt)
     b = torch.randn(Cout, generator=g)
     rv = torch.randn(N, Cout, generator=g)
-    res = _q(torch.randn(N, Cout, H, H, generator=g), dt)
+    res = _q(torch.randn(N, Cout, H, W, generator=g), dt)
     y = F.conv2d(x, w, b, padding=1) + rv[:, :, None, None] + res
-    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
-    ws = torch.full((9 * N * H * H * Cout,), float("nan"), device=_dev())
-    out = torch.empty(N, H, H, Cout, device=_dev(), dtype=torch.bfloat16)
+    geom = ops.ConvGeom(N=N, IH=H, IW=W, C0=C, C1=0, Cout=Cout)
+    ws = torch.full((9 * N * H * W * Cout,), float("nan"), device=_dev())
+    out = torch.empty(N, H, W, Cout, device=_dev(), dtype=torch.bfloat16)
     ops.conv_fwd(1, geom, _up(_nhwc(x), dt), None, _up(_w_tap(w), dt), b.to(_dev()), out, rowvec=rv.to(_dev()), rv_ld=Cout,
                  resid=_up(_nhwc(res), dt), ws=ws)
     torch.cuda.synchronize()
-    assert not torch.isnan(ws[: 9 * N * H * H * Cout]).all()           # the slabs were used
+    assert not torch.isnan(ws[: 9 * N * H * W * Cout]).all()           # the slabs were used
     assert _relerr(out, _nhwc(y)) < _tol(dt)
-    gy = _q(torch.randn(N, Cout, H, H, generator=g), dt)
-    base = _q(torch.randn(N, C, H, H, generator=g), dt)
+    gy = _q(torch.randn(N, Cout, H, W, generator=g), dt)
+    base = _q(torch.randn(N, C, H, W, generator=g), dt)
     want = base + F.conv_transpose2d(gy, w, padding=1)
     dst = _up(_nhwc(base), dt).clone()
     wT = _up(_w_tap(w).transpose(1, 2).contiguous(), dt)
