@@ -1683,9 +1683,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_pair_kernel(mdm_gemm_desc d
 // Requires: KH = KW = 3, pads 1, stride 1, no upsample, IH = OH, IW = OW in {16, 32, 64}, BM % OW == 0,
 // (BM / OW) | OH, C0 % 64 == C1 % 64 == 0, N % 64 == 0.
 // ----------------------------------------------------------------------------
-template <int BM, int NPW>
+template <int BM, int NPW, int BN = 64>
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
-    constexpr int BN = 64, NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, NSB = 4;
+    constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, NSB = 4;
+    static_assert(MI >= 1 && NI >= 1, "conv_halo: tile too small for 4 x 2 waves");
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     MDM_T(const unsigned long long t_entry = stamp_now();)
@@ -1726,12 +1727,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         const char* src = reinterpret_cast<const char*>(S + (int64_t)apix[k] * ld + cc) + lch16;
         lds_dma16((apix[k] >= 0 && cs < NCS) ? src : zlane, p < NPA ? abuf + p * 1024 : dummy);
     };
-    // ---- filter tile of (tap, slab): 64 rows (output channels) x 128 B, one piece per wave
-    const int bn = n0 + wave * 8 + (lane >> 3);
+    // ---- filter tile of (tap, slab): BN rows (output channels) x 128 B, one piece per wave (BN = 32: waves 4..7
+    // issue into the dummy page so that every wave counts the same number of DMA operations)
+    const bool b_wave = wave * 8 < BN;
+    const int bn = n0 + (b_wave ? wave * 8 : 0) + (lane >> 3);
     const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)bn * d.ldb) + lch16;
     auto issue_b = [&](int tap, int cs, int stage) {
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * 64) * 2;
-        lds_dma16((cs < NCS && !(d._p0 & 2)) ? b_row + off : zlane, bring + stage * B_BYTES + wave * 1024);
+        lds_dma16((cs < NCS && b_wave && !(d._p0 & 2)) ? b_row + off : zlane, b_wave ? bring + stage * B_BYTES + wave * 1024 : dummy);
     };
 
     // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..2 (in flight while the offset tables below are built)
@@ -1969,20 +1972,20 @@ static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of on
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW>
+template <int BM, int NPW, int BN = 64>
 static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
     const int NPA = halo_pieces(BM, d.OH, d.OW);
-    int bytes = 2 * NPA * 1024 + 4 * 64 * 128 + 1024;
-    if (bytes < BM * 64 * 4) bytes = BM * 64 * 4;                 // the tile epilogue parks the fp32 tile there
+    int bytes = 2 * NPA * 1024 + 4 * BN * 128 + 1024;
+    if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
     MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
     static int configured = 0;
     if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
-    dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / 64)));
-    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW>), grid, dim3(512), bytes, s, d);
+    dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / BN)));
+    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN>), grid, dim3(512), bytes, s, d);
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
@@ -2038,6 +2041,7 @@ static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES");
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
+static int g_halo_bn32 = []() { const char* e = getenv("MDM_HALO_BN32"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_halo = []() { const char* e = getenv("MDM_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_wgrad_lin = []() { const char* e = getenv("MDM_WGRAD_LIN"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
@@ -2153,7 +2157,8 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
             const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
             rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4>(d, s) : launch_halo<256, 6>(d, s))
                  : hb == 128 ? (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s))
-                             : (npw <= 2 ? launch_halo<64, 2>(d, s) : launch_halo<64, 3>(d, s));
+                             : g_halo_bn32 ? (npw <= 2 ? launch_halo<64, 2, 32>(d, s) : launch_halo<64, 3, 32>(d, s))
+                                           : (npw <= 2 ? launch_halo<64, 2>(d, s) : launch_halo<64, 3>(d, s));
         } else if (big) {
             rc = !lin2 ? launch_lin<128, 128, 3, 8>(d, grid, s)
                  : g_lin2 == 2 ? launch_lin2<128, 128, 3, 2, 2, 2>(d, grid, s)
