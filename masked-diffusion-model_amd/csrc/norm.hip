@@ -428,6 +428,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
     }
     const int64_t base = (int64_t)img * P;
     uint4 cx[NP], cd[NP];
+    // single-launch mode with a small slice: dy * silu'(..) is kept in fp32 registers for the apply pass instead of being
+    // recomputed (exp + rcp per element: the large-map kernels are VALU-bound, 1 wave per SIMD)
+    constexpr bool CACHE = MODE == 0 && NP <= 8;
+    float gzc[CACHE ? NP : 1][8];
     float ga[8], be[8], mean[8], rstd[8];
     float part[32];
 #pragma unroll
@@ -470,6 +474,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
                     float xh = (xv[e] - mean[e]) * rstd[e];
                     float gz = dv[e];
                     if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
+                    if (CACHE) gzc[CACHE ? i : 0][e] = gz;
                     part[16 + e] = fmaf(gz, xh, part[16 + e]); part[24 + e] += gz;          // dgamma, dbeta
                     float gg = gz * ga[e];
                     part[e] += gg; part[8 + e] = fmaf(gg, xh, part[8 + e]);                  // group sums
@@ -522,8 +527,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float xh = (xv[e] - mean[e]) * rstd[e];
-                    float gz = dv[e];
-                    if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
+                    float gz;
+                    if (CACHE) gz = gzc[CACHE ? i : 0][e];
+                    else { gz = dv[e]; if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e])); }
                     o[e] = ag[e] * gz - fmaf(xh, k2[e], k1[e]);
                     sx[e] += o[e];
                 }
