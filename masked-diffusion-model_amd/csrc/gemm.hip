@@ -1172,6 +1172,36 @@ __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds,
     }
 }
 
+
+// fp32 partial tile of a split-K contraction -> its slab, through LDS: 16-byte stores, 512 B contiguous per 32 lanes
+// (the MFMA layout stores 64-B pieces over 16 rows per instruction)
+template <int BM, int BN, int NW, int MI, int NI>
+__device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, const ZInfo& z, char* lds, int m0, int n0,
+                                                   int row_w, int col_w, int lane, int t, f32x4 (&acc)[MI][NI]) {
+    constexpr int PITCH = BN * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = row_w + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = col_w + j * 16 + 4 * (lane >> 4);
+            *reinterpret_cast<float4*>(lds + ml * PITCH + (((nl >> 2) ^ (ml & 7)) << 4)) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * z.nouter + z.outer) * ((int64_t)d.M * d.N);
+    constexpr int CPR = BN / 4;
+#pragma unroll 4
+    for (int idx = t; idx < BM * CPR; idx += 64 * NW) {
+        const int r = idx / CPR, q = idx - r * CPR;
+        const int m = m0 + r, n = n0 + q * 4;
+        if (m >= d.M || n >= d.N) continue;
+        const float4 v = *reinterpret_cast<const float4*>(lds + r * PITCH + ((q ^ (r & 7)) << 4));
+        *reinterpret_cast<float4*>(slab + (int64_t)m * d.N + n) = v;
+    }
+}
+
 #ifdef MDM_STAMP
 // debug build only (make EXTRA=-DMDM_STAMP): cycles per phase of the slab loop, summed over waves
 __device__ unsigned long long g_stamp_buf[4096 * 32];     // one 32-entry record per wave, plain stores
@@ -1630,14 +1660,19 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
             if (m < d.M) atomicAdd(&d.dbias[m], accb[i][0]);
         }
     }
+    if (d.splitk > 1 && d.ws && (d.N & 3) == 0 && !(d._p0 & 4)) {          // uniform: partial slab, wide stores through LDS
+        __syncthreads();                // every wave is done with the ring (tail DMA landed: vmcnt(0) above)
+        epilogue_tile_slab<BM, BN, NW, MI, NI>(d, z, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+    } else {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        int m = m0 + wr * WM + i * 16 + (lane & 15);
-        if (m >= d.M) continue;
+        for (int i = 0; i < MI; ++i) {
+            int m = m0 + wr * WM + i * 16 + (lane & 15);
+            if (m >= d.M) continue;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
-            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+            for (int j = 0; j < NI; ++j) {
+                int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+                if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+            }
         }
     }
 #ifdef MDM_STAMP
