@@ -1718,11 +1718,30 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_pair_kernel(mdm_gemm_desc d
 // Requires: KH = KW = 3, pads 1, stride 1, no upsample, IH = OH, IW = OW in {16, 32, 64}, BM % OW == 0,
 // (BM / OW) | OH, C0 % 64 == C1 % 64 == 0, N % 64 == 0.
 // ----------------------------------------------------------------------------
-template <int BM, int NPW, int BN = 64>
+// A "group" = TG consecutive filter taps behind one barrier (NG = 9 / TG groups per channel slab).
+template <int NPW, int APT, int NG> constexpr int halo_a_count(int g) {          // halo pieces a wave issues in group g (mod NG)
+    const int t = ((g % NG) + NG) % NG;
+    return t * APT >= NPW ? 0 : (NPW - t * APT < APT ? NPW - t * APT : APT);
+}
+template <int NPW, int APT, int D, int TG> constexpr int halo_vmcnt(int g) {      // DMA operations younger than group g's filter tiles
+    int n = (D - 1) * TG;
+    for (int j = 1; j <= D; ++j) n += halo_a_count<NPW, APT, 9 / TG>(g - j);
+    return n;
+}
+// NSB stages of TG filter tiles each, refilled D groups ahead.  TG = 3 (one filter row per barrier) cuts the barriers
+// and counted waits to a third: on the small maps a tap is 64 MFMA cycles per wave and the loop ran at ~450 cycles
+// per tap, the price of the barrier + wait + the filter-fragment round trip.  The halo pieces of the next channel
+// slab are dealt out APT per group over the first groups, so that they are all older than the filter tiles the
+// first group of that slab waits for.
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
-    constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, NSB = 4;
+    constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
+    constexpr int NG = 9 / TG;                                    // groups per channel slab
+    constexpr int D = TG == 1 ? (NSB == 4 ? 3 : NSB - 2) : NSB - 1;  // refill distance (groups)
+    constexpr int APT = (NPW + (NG - D) - 1) / (NG - D);          // halo pieces issued per group
+    static_assert(9 % TG == 0 && D >= 1 && D < NG && APT * (NG - D) >= NPW, "conv_halo: halo pieces do not fit in front of the refill distance");
     static_assert(MI >= 1 && NI >= 1, "conv_halo: tile too small for 4 x 2 waves");
-    constexpr int B_BYTES = BN * 128;
+    constexpr int B_BYTES = BN * 128, STAGE_B = TG * B_BYTES;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     MDM_T(const unsigned long long t_entry = stamp_now();)
     const int t = threadIdx.x, lane = t & 63;
@@ -1733,7 +1752,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     const int IMGS = BM > OH * OW ? BM / (OH * OW) : 1, R = IMGS > 1 ? OH : BM / OW;
     const int HRI = (R + 2) * HW2, HR = IMGS * HRI, NPA = (HR + 7) >> 3, ABUF = NPA * 1024;
     char* const bring = lds + 2 * ABUF;
-    char* const dummy = bring + NSB * B_BYTES;
+    char* const dummy = bring + NSB * STAGE_B;
     const int tiles_n = d.N / BN;
     const int mt = blockIdx.x / tiles_n, n0 = (blockIdx.x - mt * tiles_n) * BN, m0 = mt * BM;
     const int img = m0 / (OH * OW), y0 = (m0 / OW) % OH;
@@ -1767,15 +1786,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     const bool b_wave = wave * 8 < BN;
     const int bn = n0 + (b_wave ? wave * 8 : 0) + (lane >> 3);
     const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)bn * d.ldb) + lch16;
-    auto issue_b = [&](int tap, int cs, int stage) {
+    auto issue_b = [&](int tap, int cs, int lds_off) {               // lds_off: byte offset of the tile inside the ring
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * 64) * 2;
-        lds_dma16((cs < NCS && b_wave && !(d._p0 & 2)) ? b_row + off : zlane, b_wave ? bring + stage * B_BYTES + wave * 1024 : dummy);
+        lds_dma16((cs < NCS && b_wave && !(d._p0 & 2)) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
     };
 
-    // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..2 (in flight while the offset tables below are built)
+    // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..D-1 (in flight while the offset tables below are built)
 #pragma unroll
     for (int k = 0; k < NPW; ++k) issue_a(k, 0, lds);
-    issue_b(0, 0, 0); issue_b(1, 0, 1); issue_b(2, 0, 2);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+#pragma unroll
+        for (int k = 0; k < TG; ++k) issue_b((u % NG) * TG + k, u / NG, u * STAGE_B + k * B_BYTES);
 
     // ---- per-lane fragment offsets
     int a_addr[9][MI];
@@ -1809,16 +1831,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 
     int a_cur = 0;                         // byte offset of the halo buffer being multiplied
     int b_stage = 0;                       // ring stage of the current tap-slab
-#define MDM_HALO_A(tau) ((((tau) + 9) % 9) < NPW ? 1 : 0)
 #define MDM_HALO_TAP(T)                                                                                          \
     {                                                                                                            \
-        /* everything up to and including the filter tile of this tap-slab has landed (issued 3 iterations ago) */ \
-        wait_vmcnt<2 + MDM_HALO_A(T - 3) + MDM_HALO_A(T - 2) + MDM_HALO_A(T - 1)>();                             \
-        __builtin_amdgcn_s_barrier();                                                                            \
-        issue_b(((T) + 3) % 9, cs + ((T) + 3) / 9, (b_stage + 3) & 3);                                           \
-        if ((T) < NPW) issue_a((T), cs + 1, lds + (a_cur ^ a_flip));                                             \
+        if ((T) % TG == 0) {                                                                                     \
+            /* the filter tiles of this group have landed (issued D groups ago), and everything older */         \
+            wait_vmcnt<halo_vmcnt<NPW, APT, D, TG>((T) / TG)>();                                                 \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            const int rs = b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D;                                 \
+            _Pragma("unroll") for (int k = 0; k < TG; ++k)                                                       \
+                issue_b((((T) / TG + D) % NG) * TG + k, cs + ((T) / TG + D) / NG, rs * STAGE_B + k * B_BYTES);   \
+            _Pragma("unroll") for (int q = 0; q < APT; ++q)                                                      \
+                if (((T) / TG) * APT + q < NPW) issue_a(((T) / TG) * APT + q, cs + 1, lds + (a_cur ^ a_flip));   \
+        }                                                                                                        \
         const char* As = lds + a_cur;                                                                            \
-        const char* Bs = bring + b_stage * B_BYTES;                                                              \
+        const char* Bs = bring + b_stage * STAGE_B + ((T) % TG) * B_BYTES;                                       \
         bf16x8 bfr[2][NI];                                                                                       \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
@@ -1839,7 +1865,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], afr[(T) & 1][1][i], acc[i][j], 0, 0, 0); \
-        b_stage = (b_stage + 1) & 3;                                                                             \
+        if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
     bf16x8 afr[2][2][MI];                  // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
     MDM_T(const unsigned long long tstart = stamp_now();)
@@ -1850,7 +1876,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         a_cur = a_cur == 0 ? ABUF : 0;
     }
 #undef MDM_HALO_TAP
-#undef MDM_HALO_A
     wait_vmcnt<0>();
     MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
@@ -2007,20 +2032,20 @@ static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of on
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW, int BN = 64>
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
 static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
     const int NPA = halo_pieces(BM, d.OH, d.OW);
-    int bytes = 2 * NPA * 1024 + 4 * BN * 128 + 1024;
+    int bytes = 2 * NPA * 1024 + NSB * TG * BN * 128 + 1024;
     if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
     MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
     static int configured = 0;
     if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN, NSB, TG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
     dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / BN)));
-    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN>), grid, dim3(512), bytes, s, d);
+    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG>), grid, dim3(512), bytes, s, d);
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
@@ -2076,7 +2101,7 @@ static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES");
 static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
 static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
 static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
-static int g_halo_bn32 = []() { const char* e = getenv("MDM_HALO_BN32"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_halo_tg = []() { const char* e = getenv("MDM_HALO_TG"); return e ? atoi(e) : 3; }();
 static int g_halo = []() { const char* e = getenv("MDM_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_wgrad_lin = []() { const char* e = getenv("MDM_WGRAD_LIN"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
@@ -2190,10 +2215,14 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
         const int hb = (g_halo && d.splitk <= 1) ? halo_tile(d, g_big_min_tiles) : 0;
         if (hb) {
             const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
-            rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4>(d, s) : launch_halo<256, 6>(d, s))
-                 : hb == 128 ? (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s))
-                             : g_halo_bn32 ? (npw <= 2 ? launch_halo<64, 2, 32>(d, s) : launch_halo<64, 3, 32>(d, s))
-                                           : (npw <= 2 ? launch_halo<64, 2>(d, s) : launch_halo<64, 3>(d, s));
+            if (g_halo_tg == 3)          // one filter row per barrier
+                rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 64, 2, 3>(d, s) : launch_halo<256, 6, 64, 2, 3>(d, s))
+                     : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 64, 2, 3>(d, s) : npw <= 4 ? launch_halo<128, 4, 64, 2, 3>(d, s) : launch_halo<128, 6, 64, 2, 3>(d, s))
+                                 : (npw <= 2 ? launch_halo<64, 2, 64, 3, 3>(d, s) : launch_halo<64, 3, 64, 3, 3>(d, s));
+            else
+                rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4>(d, s) : launch_halo<256, 6>(d, s))
+                     : hb == 128 ? (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s))
+                                 : (npw <= 2 ? launch_halo<64, 2>(d, s) : launch_halo<64, 3>(d, s));
         } else if (big) {
             rc = !lin2 ? launch_lin<128, 128, 3, 8>(d, grid, s)
                  : g_lin2 == 2 ? launch_lin2<128, 128, 3, 2, 2, 2>(d, grid, s)
