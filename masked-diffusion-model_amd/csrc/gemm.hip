@@ -249,9 +249,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_batched_kernel(ReduceTable 
     for (int r = 0; r < REDUCE_VEC_PER_BLOCK / 256; ++r) {
         const long long i = base + r * 256 + threadIdx.x;
         if (i >= sg.total4) break;
-        float4 a = reinterpret_cast<const float4*>(sg.ws)[i];
-        for (int s = 1; s < sg.splitk; ++s) {
-            float4 b = reinterpret_cast<const float4*>(sg.ws)[(long long)s * sg.total4 + i];
+        const float4* w = reinterpret_cast<const float4*>(sg.ws) + i;
+        float4 a = w[0];
+        int s = 1;
+        for (; s + 3 < sg.splitk; s += 4) {              // four independent loads in flight (fixed summation order)
+            const float4 b0 = w[(long long)s * sg.total4], b1 = w[(long long)(s + 1) * sg.total4];
+            const float4 b2 = w[(long long)(s + 2) * sg.total4], b3 = w[(long long)(s + 3) * sg.total4];
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+        }
+        for (; s < sg.splitk; ++s) {
+            const float4 b = w[(long long)s * sg.total4];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         float4* q = reinterpret_cast<float4*>(sg.D) + i;
