@@ -313,14 +313,18 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     const int plen = (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
     __shared__ float scratch[16 * CS_PITCH];
     __shared__ float csum[16 * 8];
-    __shared__ float gsum[2 * 64], gmean[64], grstd[64];
+    __shared__ float gsum[2 * 64], gmean[64], grstd[64], gpiv[64];
+    const int64_t base = (int64_t)img * P;
     if (t < 2 * ng) {
         float a = 0.f;
         if (MODE == 2)
             for (int ch = 0; ch < chunks; ++ch) a += ws[(((int64_t)img * chunks + ch) * G + g0 + (t >> 1)) * 2 + (t & 1)];
         gsum[t] = a;
     }
-    const int64_t base = (int64_t)img * P;
+    // one pivot load per group (in flight together with the slice loads below), shared through LDS: every thread
+    // loading its 8 pivots itself and the statistics thread loading its pivot AGAIN after the reduction put a second
+    // memory round trip on the critical path of a ~3 us kernel
+    if (t < ng && g0 + t < G) gpiv[t] = gn_pivot(s0, s1, C0, C1, base, g0 + t, cpg);
     uint4 cx[NP];
     float part[16];
 #pragma unroll
@@ -332,10 +336,11 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
             cx[i] = p < pend ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
         }
     }
+    __syncthreads();
     if (MODE != 2 && on) {
         float K[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, (c + e) / cpg, cpg);
+        for (int e = 0; e < 8; ++e) K[e] = gpiv[(c + e) / cpg - g0];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (pbeg + lane + i * PL < pend) {
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     }
     if (t < ng && (g0 + t) < G) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
-        float K = gn_pivot(s0, s1, C0, C1, base, g0 + t, cpg);
+        float K = gpiv[t];
         float md = gsum[2 * t] * inv_cnt;
         float var = fmaxf(gsum[2 * t + 1] * inv_cnt - md * md, 0.f);
         float mean = K + md, rstd = rsqrtf(var + eps);
