@@ -1761,6 +1761,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     // the tile is R image rows of one image, or (maps of <= BM pixels) IMGS whole images with one halo block each
     const int IMGS = BM > OH * OW ? BM / (OH * OW) : 1, R = IMGS > 1 ? OH : BM / OW;
     const int HRI = (R + 2) * HW2, HR = IMGS * HRI, NPA = (HR + 7) >> 3, ABUF = NPA * 1024;
+    // per-lane index arithmetic below divides by HW2 and HRI (not powers of two): multiply-shift with a 20-bit
+    // reciprocal M = ceil(2^20 / d), exact while x * (M * d - 2^20) < 2^20: here x < 800, d <= 400
+    const unsigned rcp_hw2 = ((1u << 20) + HW2 - 1) / HW2, rcp_hri = ((1u << 20) + HRI - 1) / HRI;
+    const int ow_sh = __builtin_ctz(OW), rows_sh = __builtin_ctz(R * OW);       // OW, R * OW are powers of two
     char* const bring = lds + 2 * ABUF;
     char* const dummy = bring + NSB * STAGE_B;
     const int tiles_n = d.N / BN;
@@ -1776,8 +1780,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
         const int hr = (wave + 8 * k) * 8 + (lane >> 3);
-        const int il = hr / HRI, hrem = hr - il * HRI;
-        const int hy = hrem / HW2, hx = hrem - hy * HW2;
+        const int il = (int)(((unsigned)hr * rcp_hri) >> 20), hrem = hr - il * HRI;
+        const int hy = (int)(((unsigned)hrem * rcp_hw2) >> 20), hx = hrem - hy * HW2;
         const int y = y0 - 1 + hy, x = hx - 1;
         const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M && !(d._p0 & 1);
         apix[k] = ok ? ((img + il) * OH + y) * OW + x : -1;
@@ -1814,8 +1818,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = wr * WM + i * 16 + (lane & 15);
-        const int il = ml / (R * OW), mrem = ml - il * (R * OW);
-        const int r = mrem / OW, x = mrem - r * OW;
+        const int il = ml >> rows_sh, mrem = ml - (il << rows_sh);
+        const int r = mrem >> ow_sh, x = mrem - (r << ow_sh);
         const int hb = il * HRI + (r + 1) * HW2 + x + 1;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
