@@ -189,11 +189,15 @@ def main():
                             name == "mdm_splitk_reduce_pending")
         tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
         reps = 3
+        # an event pair is not free: measured on the forward contractions as 2 T(one launch) - T(two launches)
+        sched.dev_rng.advance(); step._hyper()
+        front.run(st)
+        pair_ms = front.event_overhead(st, pick(front))
         for _ in range(reps):
             sched.dev_rng.advance()
             step._hyper()
             for rec in (front, model.backward_plan):
-                for i, ms in rec.run_timed(st, pick(rec)):
+                for i, ms in rec.run_timed(st, pick(rec), pair_ms):
                     tot_ms += ms
                     if i in rec.flops:
                         tot_fl += rec.flops[i][0]
@@ -216,7 +220,8 @@ def main():
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,
                     "launches_per_step": n_launch // reps, "flops_per_step": tot_fl / reps,
-                    "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "kernel_ms_per_step": round(tot_ms / reps, 3)}
+                    "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "kernel_ms_per_step": round(tot_ms / reps, 3),
+                    "event_pair_us": round(1e3 * pair_ms, 2)}
         P = model.num_parameters()
         a_out = model.census()
         bytes_step = (38 + 8) * P + 10 * a_out               # 38 B/param (+8 EMA) + 5 passes x 2 B x A_out

@@ -145,9 +145,10 @@ class Recording:
         for i, v in other.flops.items():
             self.flops[base + i] = v
 
-    def run_timed(self, st, pick):
+    def run_timed(self, st, pick, overhead_ms=0.0):
         """Replay eagerly with a HIP event pair around every launch `pick(index, name)` selects;
-        returns [(index, ms)] (events sit on the launch stream `st`)."""
+        returns [(index, ms)] (events sit on the launch stream `st`; `overhead_ms`, see
+        `event_overhead`, is taken off every reading)."""
         lib = load()
         pairs = []
         for i, (name, fn, args) in enumerate(self.calls):
@@ -166,9 +167,38 @@ class Recording:
         for i, a, b in pairs:
             ms = f32()
             check(lib.mdm_event_elapsed_ms(a, b, C.byref(ms)))
-            out.append((i, ms.value))
+            out.append((i, max(ms.value - overhead_ms, 0.0)))
             lib.mdm_event_destroy(a); lib.mdm_event_destroy(b)
         return out
+
+    def event_overhead(self, st, pick, n=24):
+        """What an event pair adds to the launch it brackets: for the first `n` picked calls (they must be
+        idempotent: forward contractions) compare a pair around ONE launch with a pair around TWO back-to-back
+        launches; overhead = 2 T1 - T2.  Median over the sample, in ms."""
+        lib = load()
+        def timed(fn, args, reps):
+            a, b = vp(), vp()
+            check(lib.mdm_event_create(C.byref(a))); check(lib.mdm_event_create(C.byref(b)))
+            check(lib.mdm_event_record(a, st))
+            for _ in range(reps):
+                check(fn(*args, st))
+            check(lib.mdm_event_record(b, st))
+            check(lib.mdm_stream_sync(st))
+            ms = f32()
+            check(lib.mdm_event_elapsed_ms(a, b, C.byref(ms)))
+            lib.mdm_event_destroy(a); lib.mdm_event_destroy(b)
+            return ms.value
+        est = []
+        for i, (name, fn, args) in enumerate(self.calls):
+            if len(est) >= n:
+                break
+            if name == "mdm_gemm" and pick(i, name):
+                timed(fn, args, 1)                      # warm
+                t1 = min(timed(fn, args, 1) for _ in range(3))
+                t2 = min(timed(fn, args, 2) for _ in range(3))
+                est.append(2.0 * t1 - t2)
+        est.sort()
+        return max(est[len(est) // 2], 0.0) if est else 0.0
 
 
 _recording = None

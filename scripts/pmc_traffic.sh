@@ -15,16 +15,19 @@ import csv, glob, json
 def per_launch(kind):
     import os
     f = max(glob.glob(f"gpurun_out/traffic/{kind}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
-    # every kernel an mdm_gemm call launches in the bf16 step (main contraction + its split-K reduce / epilogue),
-    # divided by the number of main contraction launches = number of mdm_gemm calls
-    tot, n = 0.0, 0
+    # every kernel an mdm_gemm call launches in the bf16 step (main contraction, tap-split epilogue, batched split-K
+    # sum), divided by the number of mdm_gemm calls = optimizer steps executed (adamw launches) x calls per step
+    # (two weight gradients may share one kernel launch, so kernel launches are not counted)
+    calls_per_step = json.load(open(f"gpurun_out/traffic/{kind}.json"))["roofline"]["launches_per_step"]
+    tot, steps = 0.0, 0
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        main = any(x in k for x in ("gemm_ring_kernel", "gemm_bf16_kernel", "conv_lin_kernel", "conv_lin2_kernel", "conv_halo_kernel", "wgrad_lin_kernel"))
+        main = any(x in k for x in ("gemm_ring_kernel", "gemm_bf16_kernel", "conv_lin_kernel", "conv_lin2_kernel", "conv_halo_kernel", "wgrad_lin"))
         if main or "splitk_" in k:
             tot += float(r["Counter_Value"])
-            n += 1 if main else 0
-    return tot, n
+        if "adamw_kernel" in k:
+            steps += 1
+    return tot, steps * calls_per_step
 f, nf = per_launch("fetch"); w, nw = per_launch("write")
 out = {"kernel_family": "conv_halo / conv_lin2 / wgrad_lin / gemm_ring / gemm_bf16 kernels + the splitk_* kernels that finish them (all bf16 mdm_gemm calls)",
        "fetch_KiB_raw_per_launch": f / nf, "write_KiB_per_launch": w / nw, "launches_counted": [nf, nw],
