@@ -1581,14 +1581,19 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
         const int kl = (wave * GB + j) * B_RPP + lane / BCPR;
         const int gn = n0 + 8 * ((lane % BCPR) ^ swz_cols<BCPR>(kl));
         const int k = z.kbeg + kl;
-        const int x = k % d.OW, y = (k / d.OW) & (d.OH - 1);
+        const int x = k % d.OW, y = (k / d.OW) & (d.OH - 1), img_i = k / (d.OH * d.OW);
         b_y[j] = y;
-        b_xok[j] = gn < d.N && (unsigned)(x + dxx) < (unsigned)d.OW && !(d._p0 & 2);
+        // source pixel of output pixel (y, x) under tap (ty, tx): virtual (y s + dy, x s + dx), physical = virtual >> ups
+        // (stride 2: unet6.py:257-272; folded nearest x2 upsample: unet6.py:472).  A slab is rows_per_slab whole output
+        // rows, so the physical row advances by (rows_per_slab * s) >> ups per slab -- also across image boundaries.
+        const int vx = x * d.stride + dxx, vy = y * d.stride + dyy;
+        b_xok[j] = gn < d.N && (unsigned)vx < (unsigned)d.IW && !(d._p0 & 2);
         const bool s1 = gn >= d.C0;
         const int ld = s1 ? d.ld1 : d.ld0;
         const bf16_t* S = reinterpret_cast<const bf16_t*>(s1 ? d.src1 : d.src0);
-        b_step[j] = BK * ld * 2;
-        pb[j] = reinterpret_cast<const char*>(S + ((int64_t)k + dyy * d.OW + dxx) * ld + (s1 ? gn - d.C0 : gn));
+        const int PH = d.IH >> d.ups, PW = d.IW >> d.ups;
+        b_step[j] = ((rows_per_slab * d.stride) >> d.ups) * PW * ld * 2;
+        pb[j] = reinterpret_cast<const char*>(S + (((int64_t)img_i * PH + (vy >> d.ups)) * PW + (vx >> d.ups)) * ld + (s1 ? gn - d.C0 : gn));
     }
 
     int issued = 0, i_stage = 0;
@@ -1602,7 +1607,7 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
-            const bool ok = live && b_xok[j] && (unsigned)(b_y[j] + dyy) < (unsigned)d.OH;
+            const bool ok = live && b_xok[j] && (unsigned)(b_y[j] * d.stride + dyy) < (unsigned)d.IH;
             lds_dma16(ok ? pb[j] : zlane, stage + A_BYTES + (wave * GB + j) * 1024);
             pb[j] += b_step[j];
             b_y[j] = (b_y[j] + rows_per_slab) & (d.OH - 1);
@@ -2037,8 +2042,11 @@ int flush_wgrad(hipStream_t s) {
     return 0;
 }
 static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
-    return d.dtype == MDM_BF16 && d.layout == 2 && d.conv && d.stride == 1 && d.ups == 0 && d.IH == d.OH && d.IW == d.OW &&
-           d.OW > 0 && 64 % d.OW == 0 && (d.OH & (d.OH - 1)) == 0 && d.K % 64 == 0 && d.C0 % 8 == 0 && d.C1 % 8 == 0;
+    if (!(d.dtype == MDM_BF16 && d.layout == 2 && d.conv && d.OW > 0 && 64 % d.OW == 0 && (d.OH & (d.OH - 1)) == 0 &&
+          d.K % 64 == 0 && d.C0 % 8 == 0 && d.C1 % 8 == 0 && d.IW == d.OW * d.stride && d.IH == d.OH * d.stride))
+        return false;
+    if (d.ups == 0) return d.stride == 1 || d.stride == 2;                          // "same" conv / SamePad2d + stride 2
+    return d.stride == 1 && d.ups == 1 && ((64 / d.OW) & 1) == 0;                   // folded nearest x2 upsample
 }
 
 static int g_halo_small = []() { const char* e = getenv("MDM_HALO_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();

@@ -52,6 +52,8 @@ CONV_CASES = [
     (2, 4, 24, 0, 16, 3, 1, (1, 1, 1, 1), 1),       # nearest x2 upsample folded into the gather
     (2, 8, 64, 32, 48, 1, 1, (0, 0, 0, 0), 0),      # 1x1 skip conv over a concat
     (4, 16, 128, 0, 128, 3, 1, (1, 1, 1, 1), 0),    # big enough for several tiles
+    (4, 16, 64, 0, 64, 3, 2, (0, 0, 1, 1), 0),      # stride 2 with a 64-aligned pixel count: linear-gather weight gradient
+    (4, 8, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample, 16x16 virtual map: linear-gather weight gradient
 ]
 
 
