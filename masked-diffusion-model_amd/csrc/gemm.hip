@@ -1789,7 +1789,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         const int hy = (int)(((unsigned)hrem * rcp_hw2) >> 20), hx = hrem - hy * HW2;
         const int y = y0 - 1 + hy, x = hx - 1;
         const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M && !(d._p0 & 1);
-        apix[k] = ok ? ((img + il) * OH + y) * OW + x : -1;
+        // folded nearest x2 upsample (unet6.py:472): the map the conv sees is virtual, pixel (y, x) lives at (y>>1, x>>1)
+        apix[k] = ok ? (((img + il) * (OH >> d.ups) + (y >> d.ups)) * (OW >> d.ups) + (x >> d.ups)) : -1;
     }
     auto issue_a = [&](int k, int cs, char* abuf) {                 // k compile-time after unrolling
         const int p = wave + 8 * k;
@@ -2072,8 +2073,8 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
 static int halo_tile(const mdm_gemm_desc& d, int min_tiles) {
-    if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 &&
-          d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW &&
+    if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && (d.ups == 0 || d.ups == 1) &&
+          !(d.ups && (d.transposed || d.C1)) && d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW &&
           d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && !d.out_f32))
         return 0;
     if (d.OW == 16 || d.OW == 32 || d.OW == 64) {
@@ -2227,7 +2228,8 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
-    } else if (g_use_ring && g_use_lin && ring_eligible(d) && d.layout == 0 && d.conv && d.stride == 1 && d.ups == 0 &&
+    } else if (g_use_ring && g_use_lin && ring_eligible(d) && d.layout == 0 && d.conv && d.stride == 1 &&
+               (d.ups == 0 || (g_halo && d.splitk <= 1 && halo_tile(d, g_big_min_tiles) != 0)) &&
                d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
         // tile choice (measured per shape): the largest tile that still gives the chip ~one workgroup per CU --
         // 128x128 for the 32x32 maps, 64x128 for the 16x16 maps (+20 % over 64x64), 64x64 below that

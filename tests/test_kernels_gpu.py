@@ -54,6 +54,8 @@ CONV_CASES = [
     (4, 16, 128, 0, 128, 3, 1, (1, 1, 1, 1), 0),    # big enough for several tiles
     (4, 16, 64, 0, 64, 3, 2, (0, 0, 1, 1), 0),      # stride 2 with a 64-aligned pixel count: linear-gather weight gradient
     (4, 8, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample, 16x16 virtual map: linear-gather weight gradient
+    (32, 8, 64, 0, 128, 3, 1, (1, 1, 1, 1), 1),     # folded upsample, enough tiles for the halo kernel (forward)
+    (8, 4, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample onto an 8x8 map: whole-image halo tiles
 ]
 
 
