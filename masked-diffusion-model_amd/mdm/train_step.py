@@ -181,7 +181,14 @@ class TrainStep:
             gmul = 1.0 / self.comm.world if self.comm is not None else 1.0
             self.opt.emit_update(self.ema.shadow if self.ema is not None else None, self.max_norm, gmul)
         mk = (lambda r: _lib.GraphExec(r)) if self.use_graph else (lambda r: r)
-        self._graphs = (mk(front), [mk(c) for c in chunks], mk(tail))
+        if self.comm is None:
+            # single GPU: nothing happens between the pieces, so the whole step is ONE graph
+            whole = _lib.Recording()
+            for r in (front, chunks[0], tail):
+                whole.extend(r)
+            self._graphs = (mk(whole), [], None)
+        else:
+            self._graphs = (mk(front), [mk(c) for c in chunks], mk(tail))
 
     def run_device(self, x0, used):
         """Device-RNG step as hipGraph replays.  `x0` None = reuse the batch already in `self.x0`."""
@@ -201,5 +208,6 @@ class TrainStep:
                 self.comm.reduce_bucket(i, self.model.store.G)
         if self.comm is not None:
             self.comm.wait_all()
-        go(tail)
+        if tail is not None:
+            go(tail)
         return self.loss
