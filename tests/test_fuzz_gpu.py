@@ -1,0 +1,16 @@
+"""Randomised parity sweep of the convolution entry points over every dispatch branch (scripts/fuzz_conv.py)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_conv_shapes_match_torch(seed):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_conv
+    bad, n = fuzz_conv.run(30, seed, verbose=False)
+    assert n > 10 and bad == 0
