@@ -14,3 +14,10 @@ def test_random_conv_shapes_match_torch(seed):
     import fuzz_conv
     bad, n = fuzz_conv.run(30, seed, verbose=False)
     assert n > 10 and bad == 0
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_random_groupnorm_shapes_match_torch(seed):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_gn
+    assert fuzz_gn.run(30, seed, verbose=False) == 0
