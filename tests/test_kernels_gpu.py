@@ -379,3 +379,38 @@ def test_softmax_colsum_pool_layout_temb(dt):
         ops.timestep_embedding(t.to(dev), 4, 128, y)
         torch.cuda.synchronize()
         assert (y.cpu() - timestep_embedding(t, 128)).abs().max() < 2e-4   # sin/cos of arguments up to 1e3
+
+
+def test_deferred_weight_gradients_match_immediate_ones():
+    """defer_reduce / defer_launch (mdm_hip.h): queued split-K sums (more than one table of 96 segments) and paired
+    launches give the same gradients as self-contained calls; mdm_gemm_plan sizes the workspace slices."""
+    from mdm import ops
+    dt = "bf16"
+    g = torch.Generator().manual_seed(77)
+    shapes = [(8, 8, 64, 64), (8, 8, 64, 128), (4, 16, 64, 64)]          # N, H, C, Cout
+    jobs = []
+    for rep in range(34):                                                 # 102 deferred contractions > 96 per table
+        N, H, C, Cout = shapes[rep % 3]
+        geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
+        x = _up(_nhwc(_q(torch.randn(N, C, H, H, generator=g), dt)), dt)
+        gy = _up(_nhwc(_q(torch.randn(N, Cout, H, H, generator=g), dt)), dt)
+        nb = ops.conv_wgrad_ws_bytes(1, geom)
+        assert nb > 0
+        jobs.append((geom, x, gy, nb))
+    want, got = [], []
+    for geom, x, gy, nb in jobs:
+        ws = torch.empty(nb // 4, device=_dev())
+        gw = torch.full((9, geom.Cout, geom.C0), 0.5, device=_dev())
+        ops.conv_wgrad(1, geom, gy, x, None, gw, ws=ws)                   # self-contained: own reduce launch
+        want.append(gw)
+    keep = []
+    for i, (geom, x, gy, nb) in enumerate(jobs):
+        ws = torch.full((nb // 4,), float("nan"), device=_dev())
+        gw = torch.full((9, geom.Cout, geom.C0), 0.5, device=_dev())
+        ops.conv_wgrad(1, geom, gy, x, None, gw, ws=ws, defer=True, defer_launch=(i % 2 == 0))
+        keep.append(ws); got.append(gw)
+    ops.splitk_reduce_pending()
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
+        assert float((b - 0.5).abs().max()) > 0.1                         # accumulated onto the initial value, and non-trivial
