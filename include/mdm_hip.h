@@ -113,6 +113,9 @@ int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
 int mdm_splitk_reduce_pending(void* stream);
 /* Launches every queued (defer_launch) contraction. */
 int mdm_gemm_flush(void* stream);
+/* Forgets every queued launch and reduction of this host thread WITHOUT running them (error recovery: a launch
+ * sequence that was abandoned half-way must not leave pointers behind for the next mdm_splitk_reduce_pending). */
+int mdm_gemm_discard_pending(void);
 /* What mdm_gemm would choose for this descriptor given unlimited workspace: the split count and the
  * workspace bytes it needs (0 when it would not use partial slabs).  No launch. */
 int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out);

@@ -2316,6 +2316,11 @@ extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
 }
 extern "C" int mdm_splitk_reduce_pending(void* stream) { return mdm::reduce_pending(mdm::pick_stream(stream)); }
 extern "C" int mdm_gemm_flush(void* stream) { return mdm::flush_wgrad(mdm::pick_stream(stream)); }
+extern "C" int mdm_gemm_discard_pending(void) {           // error recovery: forget every queued launch / reduction
+    mdm::g_pending_wgrad.clear();
+    mdm::g_pending.clear();
+    return 0;
+}
 extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
     if (!splitk_out || !ws_bytes_out) { mdm::set_error("gemm_plan: null output"); return -1; }
     return mdm::gemm_launch(desc_host, nullptr, splitk_out, ws_bytes_out);

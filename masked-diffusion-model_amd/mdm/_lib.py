@@ -40,6 +40,7 @@ _PROTOS = {
     "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
     "mdm_splitk_reduce_pending": ([vp], i32),
     "mdm_gemm_flush": ([vp], i32),
+    "mdm_gemm_discard_pending": ([], i32),
     "mdm_gemm_plan": ([C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i64)], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
@@ -107,7 +108,9 @@ def load():
 
 def check(rc, what=""):
     if rc != 0:
-        raise RuntimeError(f"libmdm_hip {what} failed ({rc}): {load().mdm_last_error().decode()}")
+        msg = load().mdm_last_error().decode()
+        load().mdm_gemm_discard_pending()           # a failed sequence must not leave queued launches / reductions behind
+        raise RuntimeError(f"libmdm_hip {what} failed ({rc}): {msg}")
 
 
 class Recording:
@@ -133,10 +136,14 @@ class Recording:
 
     def run(self, st=None):
         st = stream() if st is None else st
-        for name, fn, args in self.calls:
-            rc = fn(*args, st)
-            if rc != 0:
-                check(rc, name)
+        try:
+            for name, fn, args in self.calls:
+                rc = fn(*args, st)
+                if rc != 0:
+                    check(rc, name)
+        except BaseException:
+            load().mdm_gemm_discard_pending()       # an abandoned sequence must not leave queued launches behind
+            raise
 
     def extend(self, other):
         base = len(self.calls)
