@@ -2114,6 +2114,7 @@ static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
 static int g_use_ring = []() { const char* e = getenv("MDM_NO_RING"); return (e && e[0] == '1') ? 0 : 1; }();
 static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_wgrad_min_slabs = []() { const char* e = getenv("MDM_WGRAD_MIN_SLABS"); return e ? atoi(e) : 4; }();
 static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
 static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
 static int g_lin_tile = []() { const char* e = getenv("MDM_LIN_TILE"); return e ? atoi(e) : 0; }();
@@ -2174,7 +2175,7 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
     if (d.layout == 2) {
         if (d.splitk <= 0) {     // auto: aim at ~g_wgrad_blocks workgroups, at least 4 k-steps each
             int64_t want = (big ? g_wgrad_blocks : 4 * g_wgrad_blocks) / (tiles * zouter);
-            int64_t cap = d.K / (4 * BK);
+            int64_t cap = d.K / (g_wgrad_min_slabs * BK);
             d.splitk = (int)(want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want));
             if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
         }
