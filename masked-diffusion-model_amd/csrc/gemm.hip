@@ -2114,6 +2114,7 @@ static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
 static int g_use_ring = []() { const char* e = getenv("MDM_NO_RING"); return (e && e[0] == '1') ? 0 : 1; }();
 static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
 static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
+static int g_wgrad_big_min = []() { const char* e = getenv("MDM_WGRAD_BIG_MIN"); return e ? atoi(e) : 1; }();
 static int g_wgrad_min_slabs = []() { const char* e = getenv("MDM_WGRAD_MIN_SLABS"); return e ? atoi(e) : 4; }();
 static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
 static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
@@ -2168,7 +2169,7 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
     // tile choice: 128x128 when that still yields enough workgroups; weight gradients (layout 2: small
     // output, huge reduction, split-K supplies the parallelism) take the big tile whenever it fits.
     const bool big = d.dtype == MDM_BF16 && !g_force_small && d.N >= 128 && d.M >= 128 &&
-                     (d.layout == 2 ? (!g_wgrad_small && d.K >= 2048) : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= g_big_min_tiles);
+                     (d.layout == 2 ? (!g_wgrad_small && d.K >= 2048 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= g_wgrad_big_min) : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= g_big_min_tiles);
     const int BM = d.dtype == MDM_F32 ? 64 : (big ? 128 : 64), BN = BM;
     const int BK = d.dtype == MDM_F32 ? 16 : 64;
     int64_t tiles = (int64_t)cdiv(d.M, BM) * cdiv(d.N, BN);
