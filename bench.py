@@ -190,11 +190,10 @@ def main():
         tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
         reps = 3
         # an event pair is not free: measured on the forward contractions as 2 T(one launch) - T(two launches)
-        sched.dev_rng.advance(); step._hyper()
+        step._hyper()
         front.run(st)
         pair_ms = front.event_overhead(st, pick(front))
         for _ in range(reps):
-            sched.dev_rng.advance()
             step._hyper()
             for rec in (front, model.backward_plan):
                 for i, ms in rec.run_timed(st, pick(rec), pair_ms):

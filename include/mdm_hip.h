@@ -224,6 +224,16 @@ int mdm_loss_fwd_bwd(int dtype, const void* pred, const float* x_in, const float
  *   x_t   <- x_t + (d_next - d_t)  [momentum]  |  x_t <- d_next  [base]     (mdm_sampler_update) */
 int mdm_sampler_x0(int dtype, const void* pred_nhwc, int Cp, const float* x_in, const float* s,
                    int N, int C, int H, int W, float* pred_nchw, float* shifted0, float* x0_hat, void* stream);
+/* rng = {seed, offset} (uint64 x2, device): ++offset in stream order.  Every step / graph replay starts with it (the
+ * kernels key Philox by (seed, offset, stream id, element)). */
+int mdm_rng_advance(uint64_t* rng, void* stream);
+/* Device-side per-step parameters (so that one reverse step is one hipGraph replayed T times): with step = *step_ctr,
+ * i = T-1-step, t = timesteps[i], t_next = t-1 (t when i == 0) writes time_out[n] = t, ratio_out[n] = ratio_tab[t-1]
+ * (optional), amt_t[n] = amount_tab[t-1], amt_next[n] = amount_tab[t_next-1], then ++*step_ctr and ++rng[1]
+ * (sampler.py:137-170; the Philox offset bump of the host path). */
+int mdm_sampler_step_params(const int32_t* timesteps, int T, int32_t* step_ctr, const double* ratio_tab,
+                            const double* amount_tab, int n, float* time_out, double* ratio_out, double* amt_t,
+                            double* amt_next, uint64_t* rng, void* stream);
 int mdm_sampler_update(const float* d_t, const float* d_next, float* x_t, float* diff, int momentum,
                        int64_t n, void* stream);
 

@@ -218,6 +218,32 @@ __global__ void sampler_update_kernel(const float* d_t, const float* d_next, flo
     x_t[i] = momentum ? x_t[i] + df : d_next[i];
 }
 
+// The Philox offset lives in device memory and is bumped ON the device, in stream order: a host counter copied over
+// asynchronously from pinned memory is read when the copy executes, by which time a host that runs ahead of the GPU
+// (it always does under hipGraph replay) may have bumped it again -- steps would skip or repeat offsets.
+__global__ void rng_advance_kernel(unsigned long long* rng) { rng[1] += 1ull; }
+
+// Per-step parameters of the reverse sampler, produced ON the device so that a whole reverse step can be one hipGraph
+// replayed T times with no host work in between (sampler.py:137-170): step counter -> timestep t of this step,
+// t_next = t - 1 (t on the last step), the shift ratio and the two degrade amounts from the schedule tables, and the
+// Philox offset bump the host path does with DeviceRng.advance().
+__global__ void sampler_step_kernel(const int* timesteps, int T, int* step_ctr, const double* ratio_tab, const double* amount_tab,
+                                    int n, float* time_out, double* ratio_out, double* amt_t, double* amt_next,
+                                    unsigned long long* rng) {
+    const int step = *step_ctr;
+    const int i = T - 1 - step;
+    const int t = timesteps[i < 0 ? 0 : i];
+    const int tn = i > 0 ? t - 1 : t;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        time_out[j] = (float)t;
+        if (ratio_out) ratio_out[j] = ratio_tab[t - 1];
+        amt_t[j] = amount_tab[t - 1];
+        amt_next[j] = amount_tab[tn - 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { *step_ctr = step + 1; rng[1] += 1ull; }
+}
+
 static inline int sgrid(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -307,6 +333,23 @@ extern "C" int mdm_sampler_x0(int dtype, const void* pred_nhwc, int Cp, const fl
         hipLaunchKernelGGL((sampler_x0_kernel<float>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)pred_nhwc, Cp, x_in, s, C, H * W, total, pred_nchw, shifted0, x0_hat);
     return launch_status("sampler_x0");
+}
+
+extern "C" int mdm_rng_advance(uint64_t* rng, void* stream) {
+    MDM_REQUIRE(rng, "rng_advance: null state");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(rng));
+    return launch_status("rng_advance");
+}
+
+extern "C" int mdm_sampler_step_params(const int32_t* timesteps, int T, int32_t* step_ctr, const double* ratio_tab,
+                                       const double* amount_tab, int n, float* time_out, double* ratio_out, double* amt_t,
+                                       double* amt_next, uint64_t* rng, void* stream) {
+    MDM_REQUIRE(timesteps && step_ctr && amount_tab && time_out && amt_t && amt_next && rng && T > 0 && n > 0,
+                "sampler_step_params: bad arguments");
+    MDM_REQUIRE(!ratio_out || ratio_tab, "sampler_step_params: ratio_out needs the ratio table");
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, timesteps, T, step_ctr, ratio_tab, amount_tab,
+                       n, time_out, ratio_out, amt_t, amt_next, reinterpret_cast<unsigned long long*>(rng));
+    return launch_status("sampler_step_params");
 }
 
 extern "C" int mdm_sampler_update(const float* d_t, const float* d_next, float* x_t, float* diff, int momentum, int64_t n,

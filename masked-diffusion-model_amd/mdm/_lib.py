@@ -62,6 +62,8 @@ _PROTOS = {
     "mdm_loss_fwd_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp], i32),
     "mdm_sampler_x0": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp], i32),
     "mdm_sampler_update": ([vp, vp, vp, vp, i32, i64, vp], i32),
+    "mdm_rng_advance": ([vp, vp], i32),
+    "mdm_sampler_step_params": ([vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
     "mdm_sqnorm": ([vp, i64, vp, vp], i32),
     "mdm_adamw_ema": ([vp, vp, vp, vp, vp, vp, i64, vp, vp, f32, f32, vp], i32),
     "mdm_cast_bf16": ([vp, vp, i64, vp], i32),

@@ -15,6 +15,7 @@ What is different from the reference loop (same arithmetic, same RNG order in re
 from __future__ import annotations
 
 import numpy as np
+import os
 import torch
 
 from . import _lib, ops
@@ -77,6 +78,75 @@ class Sampler:
         ops.nchw_to_nhwc(_lib.F32, pred, nh, n, c, h, w, cp)
         return nh, cp, _lib.F32
 
+    def _sample_graph(self, model, timesteps, x_t, dep, mode):
+        """The same loop as `_sample_mean_shift_momentum` (history off, device RNG) with ONE hipGraph per reverse step:
+        the per-step scalars (t, t-1, shift ratio, degrade amounts, Philox offset) are produced on the device by
+        `mdm_sampler_step_params` from a step counter, so T replays need no host work in between."""
+        from .scheduler import SHIFT_KINDS, _fill_mode
+        a, S = self.args, self.Scheduler
+        dev = S.device
+        T = len(timesteps)
+        n, c, hw = a.sample_num, a.out_channel, a.data_size
+        HW = hw * hw
+        st = a.shift_type
+        if st not in SHIFT_KINDS:
+            raise UnboundLocalError(f"shift_time undefined for shift_type={st!r}")
+        kind = SHIFT_KINDS[st]
+        per_col = int(S.reference_quirks and kind in (3, 4) and n == hw and n > 1)
+        sel = a.select_degrade_pixel
+        fm, fc = _fill_mode(a.mean_option, a.mean_area)
+        Cm = S._check_degrade_args(x_t)
+        amount_tab = (S.pixels_dev if sel == "indexing" else S.ratio_dev).to(dev, torch.float64).contiguous()
+        ratio_tab = S.ratio_dev.to(dev, torch.float64).contiguous()
+        ts_dev = torch.as_tensor([int(t) for t in timesteps], dtype=torch.int32, device=dev)
+        ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        f64 = lambda: torch.empty(n, dtype=torch.float64, device=dev)
+        ratio, amt_t, amt_next = f64(), f64(), f64()
+        img = lambda: torch.empty_like(x_t)
+        s, x_in, x0_hat, d_t, d_next, m_t, diff = img(), img(), img(), img(), img(), img(), torch.zeros_like(x_t)
+        m_next = torch.zeros(n, c, hw, hw, device=dev)
+        mi_t, mi_next = (img(), img()) if sel == "indexing" else (None, None)
+        mp = torch.empty(n, c, device=dev)
+        rng = S.dev_rng.dev
+
+        def degrade(amount, stream_id, mask_src, out, mask_out, mi):
+            if mask_src is not None:                      # degrade_with_mask (scheduler.py:572-598)
+                call("mdm_degrade", ptr(x0_hat), None, ptr(mask_src), None, 1, ptr(rng), 0, n, c, HW, c, fm, fc, ptr(out), None, ptr(mp), stream())
+            elif sel == "indexing":
+                call("mdm_index_mask", ptr(amount), 1, ptr(rng), stream_id, n, c, HW, ptr(mi), stream())
+                call("mdm_degrade", ptr(x0_hat), None, ptr(mi), None, 1, ptr(rng), stream_id, n, c, HW, c, fm, fc, ptr(out), ptr(mask_out), ptr(mp), stream())
+            else:
+                call("mdm_degrade", ptr(x0_hat), None, None, ptr(amount), 1, ptr(rng), stream_id, n, c, HW, Cm, fm, fc, ptr(out), ptr(mask_out), ptr(mp), stream())
+
+        def emit(update):
+            call("mdm_sampler_step_params", ptr(ts_dev), T, ptr(ctr), ptr(ratio_tab), ptr(amount_tab), n, ptr(model.t_in),
+                 ptr(ratio) if kind != 0 else None, ptr(amt_t), ptr(amt_next), ptr(rng), stream())
+            call("mdm_shift", ptr(x_t), None, ptr(ratio) if kind != 0 else None, ptr(rng), 2, kind, float(getattr(a, "noise_mean", 0.0)),
+                 per_col, n, c, hw, hw, ptr(s), ptr(x_in), model.dt, ptr(model.x_in.data), model.cin_p, stream())
+            _lib._recording.extend(model.forward_plan)
+            call("mdm_sampler_x0", model.dt, ptr(model.y_out.data), model.cout_p, ptr(x_in), ptr(s), n, c, hw, hw, None, None,
+                 ptr(x0_hat), stream())
+            if dep == "independent":
+                degrade(amt_t, 3, None, d_t, m_t, mi_t)
+                degrade(amt_next, 4, None, d_next, m_next, mi_next)
+            else:
+                degrade(None, 0, m_next, d_t, None, None)
+                degrade(amt_next, 4, None, d_next, m_next, mi_next)
+            if update:
+                call("mdm_sampler_update", ptr(d_t), ptr(d_next), ptr(x_t), ptr(diff), int(mode == "base_momentum"), x_t.numel(), stream())
+
+        with _lib.Recording() as body:
+            emit(True)
+        with _lib.Recording() as last:
+            emit(False)                                      # i == 0: base_sampling breaks before the write, momentum skips it
+        keep = (ts_dev, ctr, ratio, amt_t, amt_next, s, x_in, d_t, d_next, m_t, m_next, mi_t, mi_next, mp, diff, amount_tab, ratio_tab)
+        gb, gl = _lib.GraphExec(body), _lib.GraphExec(last)
+        for _ in range(T - 1):
+            gb.launch()
+        gl.launch()
+        self._graph_keep = (keep, gb, gl)
+        return x0_hat
+
     def _sample_mean_shift_momentum(self, model, timesteps):
         from .unet import UNet
         a, S = self.args, self.Scheduler
@@ -97,6 +167,9 @@ class Sampler:
         hist = None
         if hist_mode:
             hist = {k: torch.zeros(T + 1, n, c, hw, hw, device=dev) for k in HISTORY_NAMES}
+        if (fused and not hist_mode and S.rng_mode == "device" and model.use_graph
+                and os.environ.get("MDM_SAMPLER_GRAPH", "1") != "0"):
+            return self._sample_graph(model, timesteps, x_t, dep, mode), []
         x0_hat = torch.empty_like(x_t)
         pred_nchw = torch.empty_like(x_t) if hist_mode else None
         shifted0 = torch.empty_like(x_t) if hist_mode else None

@@ -29,17 +29,16 @@ SHIFT_KINDS = {"non_shift": 0, "1-d_constant": 1, "3-d_constant": 2, "noise_redu
 
 
 class DeviceRng:
-    """Philox key/offset pair living in device memory: `advance()` before every step or graph replay."""
+    """Philox key/offset pair living in device memory.  `advance()` bumps the offset ON the device, in stream order
+    (recorded like any other launch, so a captured step bumps it on every replay); a host-side counter copied over
+    asynchronously would be read late by a GPU that the host runs ahead of."""
 
     def __init__(self, device, seed=0):
-        self.host = torch.zeros(2, dtype=torch.int64).pin_memory() if torch.cuda.is_available() else torch.zeros(2, dtype=torch.int64)
-        self.host[0] = seed
-        self.dev = torch.zeros(2, dtype=torch.int64, device=device)
-        self.dev.copy_(self.host)
+        self.dev = torch.tensor([int(seed), 0], dtype=torch.int64, device=device) if torch.cuda.is_available() \
+            else torch.tensor([int(seed), 0], dtype=torch.int64)
 
     def advance(self):
-        self.host[1] += 1
-        self.dev.copy_(self.host, non_blocking=True)
+        call("mdm_rng_advance", ptr(self.dev), stream())
 
 
 def _fill_mode(mean_option, mean_area):

@@ -150,6 +150,7 @@ class TrainStep:
         N, C, H, W = m.N, m.cin, m.H, m.W
         rng = ptr(S.dev_rng.dev)
         n_used = self.used_dev.numel()
+        S.dev_rng.advance()                 # first launch of the step (part of the captured graph): a fresh Philox offset
         call("mdm_draw_timesteps", rng, ptr(self.used_dev), n_used, ptr(self.table_dev), ptr(self.wtab_dev), N,
              ptr(m.t_in), ptr(self.amount), ptr(self.w), ptr(self.tidx), stream())
         call("mdm_draw_timesteps", rng, ptr(self.used_dev), n_used, ptr(S.ratio_dev), None, N,
@@ -198,7 +199,6 @@ class TrainStep:
         if self._graphs is None:
             self._build_graphs()
         front, chunks, tail = self._graphs
-        self.S.dev_rng.advance()
         self._hyper()
         go = (lambda g: g.launch()) if self.use_graph else (lambda g: g.run())
         go(front)

@@ -241,3 +241,30 @@ def test_sampler_bf16_and_history_off(golden):
     assert hist == []
     rel = np.linalg.norm(x0.cpu().numpy() - g["samp0_x0"]) / np.linalg.norm(g["samp0_x0"])
     assert rel < 5e-2, rel
+
+
+@pytest.mark.parametrize("dep,mode,sel,sched", [("independent", "base_momentum", "thresholding", "linear"),
+                                               ("dependent_prev", "base_sampling", "thresholding", "linear"),
+                                               ("independent", "base_sampling", "indexing", "log")])
+def test_sampler_one_graph_per_step_equals_the_host_driven_loop(dep, mode, sel, sched, monkeypatch):
+    """Device RNG, history off: the reverse step as ONE hipGraph with device-side step parameters
+    (mdm_sampler_step_params) reproduces the host-driven loop (same Philox offsets, same kernels)."""
+    import mdm
+    from oracle.unet_ref import random_params
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MDM_SAMPLER_GRAPH", flag)
+        model = mdm.UNet(TINY, N=4, H=16, W=16, dtype=1, params=random_params(TINY)).eval()
+        a = base_args(data_size=16, ddpm_schedule=sched, ddpm_num_steps=8, select_degrade_pixel=sel, degrade_channel="1-channel",
+                      shift_type="noise_with_perturbation", sampling_mask_dependency=dep, momentum_adaptive=mode, sample_num=4,
+                      sample_latent_shape="uniform", sample_history=False, rng_mode="device", seed=5)
+        s = mdm.Scheduler(a)
+        s.update_ddpm_num_steps(8)
+        smp = mdm.Sampler(None, a, s, [None] * 3)
+        seed_all(401)
+        x0, hist = smp.sample(model, s.get_timesteps_epoch(0, 1))
+        torch.cuda.synchronize()
+        assert hist == [] and bool(torch.isfinite(x0).all())
+        outs.append(x0.cpu().numpy().copy())
+    rel = np.linalg.norm(outs[0] - outs[1]) / (np.linalg.norm(outs[0]) + 1e-12)
+    assert rel < 1e-3, rel
