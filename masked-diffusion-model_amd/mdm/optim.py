@@ -26,7 +26,13 @@ class AdamW:
         self.m = torch.zeros_like(st.P)
         self.v = torch.zeros_like(st.P)
         self.t = 0
-        self.hp_host = torch.zeros(8).pin_memory()
+        # the 8-float hyper-parameter block travels by async H2D copy from pinned memory, which is read when the copy
+        # EXECUTES: a host that runs ahead of the GPU must not overwrite a block whose copy has not run yet -> a ring of
+        # pinned slots, each guarded by an event recorded behind its copy
+        self._hp_slots = 64
+        self.hp_host = torch.zeros(self._hp_slots, 8).pin_memory() if torch.cuda.is_available() else torch.zeros(self._hp_slots, 8)
+        self._hp_events = [None] * self._hp_slots
+        self._hp_k = 0
         self.hp = torch.zeros(8, device=st.P.device)
         self.sqnorm = torch.zeros(1, device=st.P.device)
 
@@ -36,10 +42,19 @@ class AdamW:
         if advance:
             self.t += 1
         b1, b2 = g["betas"]
-        self.hp_host[0] = g["lr"]; self.hp_host[1] = b1; self.hp_host[2] = b2; self.hp_host[3] = g["eps"]
-        self.hp_host[4] = g["weight_decay"]
-        self.hp_host[5] = 1 - b1 ** self.t; self.hp_host[6] = 1 - b2 ** self.t; self.hp_host[7] = ema_decay
-        self.hp.copy_(self.hp_host, non_blocking=True)
+        k = self._hp_k
+        self._hp_k = (k + 1) % self._hp_slots
+        if self._hp_events[k] is not None:
+            self._hp_events[k].synchronize()          # the copy that last read this slot has executed
+        h = self.hp_host[k]
+        h[0] = g["lr"]; h[1] = b1; h[2] = b2; h[3] = g["eps"]
+        h[4] = g["weight_decay"]
+        h[5] = 1 - b1 ** self.t; h[6] = 1 - b2 ** self.t; h[7] = ema_decay
+        self.hp.copy_(h, non_blocking=True)
+        if self.hp.is_cuda:
+            ev = self._hp_events[k] or torch.cuda.Event()
+            ev.record()
+            self._hp_events[k] = ev
 
     def emit_update(self, ema_buf=None, max_norm=1.0, gmul=1.0):
         """Enqueue (or record) grad-norm + clip + AdamW + EMA + bf16 shadow over the flat buffers."""
