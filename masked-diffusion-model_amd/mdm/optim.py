@@ -28,10 +28,10 @@ class AdamW:
         self.t = 0
         # the 8-float hyper-parameter block travels by async H2D copy from pinned memory, which is read when the copy
         # EXECUTES: a host that runs ahead of the GPU must not overwrite a block whose copy has not run yet -> a ring of
-        # pinned slots, each guarded by an event recorded behind its copy
+        # pinned slots in groups of 16, each group guarded by one event recorded behind its last copy
         self._hp_slots = 64
         self.hp_host = torch.zeros(self._hp_slots, 8).pin_memory() if torch.cuda.is_available() else torch.zeros(self._hp_slots, 8)
-        self._hp_events = [None] * self._hp_slots
+        self._hp_events = [None] * (self._hp_slots // 16)
         self._hp_k = 0
         self.hp = torch.zeros(8, device=st.P.device)
         self.sqnorm = torch.zeros(1, device=st.P.device)
@@ -44,17 +44,18 @@ class AdamW:
         b1, b2 = g["betas"]
         k = self._hp_k
         self._hp_k = (k + 1) % self._hp_slots
-        if self._hp_events[k] is not None:
-            self._hp_events[k].synchronize()          # the copy that last read this slot has executed
+        g16 = k // 16
+        if k % 16 == 0 and self._hp_events[g16] is not None:
+            self._hp_events[g16].synchronize()        # every copy that read this group of slots has executed
         h = self.hp_host[k]
         h[0] = g["lr"]; h[1] = b1; h[2] = b2; h[3] = g["eps"]
         h[4] = g["weight_decay"]
         h[5] = 1 - b1 ** self.t; h[6] = 1 - b2 ** self.t; h[7] = ema_decay
         self.hp.copy_(h, non_blocking=True)
-        if self.hp.is_cuda:
-            ev = self._hp_events[k] or torch.cuda.Event()
+        if self.hp.is_cuda and k % 16 == 15:
+            ev = self._hp_events[g16] or torch.cuda.Event()
             ev.record()
-            self._hp_events[k] = ev
+            self._hp_events[g16] = ev
 
     def emit_update(self, ema_buf=None, max_norm=1.0, gmul=1.0):
         """Enqueue (or record) grad-norm + clip + AdamW + EMA + bf16 shadow over the flat buffers."""
