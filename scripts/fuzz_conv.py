@@ -41,12 +41,17 @@ def run(n_cases, seed, verbose=True):
       ops.conv_fwd(1, geom, s0, s1, wt, b.to(dev), out, ws=ws)
       e_f = rel(out, nhwc(y.detach()))
       gyh = up(nhwc(gy))
-      e_d = 0.0
-      if s == 1 and not u:
-          wT = up(w.permute(2, 3, 1, 0).reshape(k * k, C, Co).contiguous())
+      wT = up(w.permute(2, 3, 1, 0).reshape(k * k, C, Co).contiguous())
+      gx = nhwc(xr.grad)
+      if u:       # data gradient on the virtual (upsampled) map, then the 2x2 sum pool the model applies
+          tmp = torch.empty(N, geom.VH, geom.VW, C0, device=dev, dtype=bf)
+          ops.conv_dgrad_t(1, geom, gyh, wT, tmp, 0, ws=ws)
+          d0 = torch.empty(N, H, H, C0, device=dev, dtype=bf)
+          ops.sumpool2(1, tmp, d0, 0, N, H, H, C0)
+          e_d = rel(d0, gx)
+      else:
           d0 = torch.empty(N, H, H, C0, device=dev, dtype=bf); d1 = torch.empty(N, H, H, C1, device=dev, dtype=bf) if C1 else None
           ops.conv_dgrad_t(1, geom, gyh, wT, d0, 0, d1, 0, ws=ws)
-          gx = nhwc(xr.grad)
           e_d = max(rel(d0, gx[..., :C0]), rel(d1, gx[..., C0:]) if C1 else 0.0)
       gw = torch.zeros(k * k, Co, C, device=dev)
       ops.conv_wgrad(1, geom, gyh, s0, s1, gw, ws=ws)
