@@ -1258,8 +1258,8 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     for (int j = 0; j < GA; ++j) {
         const int gm = m0 + 8 * (wave * GA + j) + r_sub;
         RowPix rp = decode_row(d, gm < d.M ? gm : 0);
-        const int by = d.transposed ? rp.oy + d.pad_t : rp.oy - d.pad_t;
-        const int bx = d.transposed ? rp.ox + d.pad_l : rp.ox - d.pad_l;
+        const int by = d.transposed ? rp.oy + d.pad_t : rp.oy * d.stride - d.pad_t;     // stride 2: forward only (host rule)
+        const int bx = d.transposed ? rp.ox + d.pad_l : rp.ox * d.stride - d.pad_l;
         unsigned vm = 0;
         for (int ty = 0; ty < d.KH; ++ty)
             for (int tx = 0; tx < d.KW; ++tx) {
@@ -2230,7 +2230,8 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
-    } else if (g_use_ring && g_use_lin && ring_eligible(d) && d.layout == 0 && d.conv && d.stride == 1 &&
+    } else if (g_use_ring && g_use_lin && ring_eligible(d) && d.layout == 0 && d.conv &&
+               (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0 && g_lin2 == 3 && d.C0 <= 4096 && d.C1 <= 4096)) &&
                (d.ups == 0 || (g_halo && d.splitk <= 1 && halo_tile(d, g_big_min_tiles) != 0)) &&
                d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
         // tile choice (measured per shape): the largest tile that still gives the chip ~one workgroup per CU --
