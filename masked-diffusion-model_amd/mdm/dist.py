@@ -33,25 +33,31 @@ def init_from_env(backend=None):
 
 
 class GradComm:
-    def __init__(self, group=None, bucket_bytes=32 << 20):
+    def __init__(self, group=None, bucket_bytes=32 << 20, tail_bytes=4 << 20):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_bytes = bucket_bytes
+        self.tail_bytes = min(tail_bytes, bucket_bytes)
         self.buckets = []        # (lo, hi) element ranges of the flat gradient buffer, in completion order
         self._handles = []
 
     # ---- planning --------------------------------------------------------------------------
     @staticmethod
-    def plan_buckets(marks, total, bucket_elems):
+    def plan_buckets(marks, total, bucket_elems, tail_elems=None):
         """marks: [(n_calls_after_piece, lowest_param_offset_complete)] in backward order (offsets
         non-increasing, the last one 0).  -> (cuts, buckets): after call index cuts[i], the gradient
-        slice buckets[i] = (lo, hi) is final.  Buckets tile [0, total) from the top down."""
+        slice buckets[i] = (lo, hi) is final.  Buckets tile [0, total) from the top down.
+        `tail_elems`: once less than two buckets are left, a bucket closes at half of what is left (never
+        below tail_elems): only the LAST exchange is exposed behind the backward, so it should be small."""
         cuts, buckets = [], []
         hi = total
         for n_calls, lo in marks:
             last = lo == 0
-            if (hi - lo >= bucket_elems) or (last and hi > lo):
+            want = bucket_elems
+            if tail_elems is not None and hi < 2 * bucket_elems:
+                want = max(tail_elems, hi // 2)
+            if (hi - lo >= want) or (last and hi > lo):
                 if cuts and cuts[-1] == n_calls:       # no new calls since the previous cut: widen it
                     buckets[-1] = (lo, buckets[-1][1])
                 else:
@@ -65,7 +71,7 @@ class GradComm:
         marks = list(model.bwd_marks)
         n_total = len(model.backward_plan.calls)
         marks[-1] = (n_total, 0)
-        cuts, self.buckets = self.plan_buckets(marks, model.store.size, self.bucket_bytes // 4)
+        cuts, self.buckets = self.plan_buckets(marks, model.store.size, self.bucket_bytes // 4, tail_elems=self.tail_bytes // 4)
         cuts[-1] = n_total
         return cuts
 

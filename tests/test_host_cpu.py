@@ -134,6 +134,12 @@ def test_bucket_planning():
     assert b1 == [(0, 1000)] and cuts1 == [50]
     net_marks = [(5, 7), (9, 0)]
     assert GradComm.plan_buckets(net_marks, 8, 1) == ([5, 9], [(7, 8), (0, 7)])
+    # tapered tail: the exposed last exchange shrinks geometrically, the plan still tiles [0, total)
+    fine = [(k, 1000 - 10 * k) for k in range(1, 101)]
+    c2, b2 = GradComm.plan_buckets(fine, 1000, 300, tail_elems=40)
+    assert b2[0][1] == 1000 and b2[-1][0] == 0 and all(b2[i][0] == b2[i + 1][1] for i in range(len(b2) - 1))
+    sizes = [hi - lo for lo, hi in b2]
+    assert sizes[0] >= 300 and sizes[-1] <= 80 and len(b2) > len(GradComm.plan_buckets(fine, 1000, 300)[1])
 
 
 def test_ema_and_lr_schedules_per_call_site_arguments():
