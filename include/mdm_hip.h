@@ -105,6 +105,15 @@ typedef struct mdm_gemm_desc {
      * block), or is launched by mdm_gemm_flush() / mdm_splitk_reduce_pending().  Its operands must stay
      * untouched until then. */
     int32_t defer_launch;
+    /* Fused GroupNorm backward (unet6.py:291-293 backward) in the epilogue of the DATA GRADIENT of the conv that
+     * consumes the normalised tensor, on the whole-image tiles of the 4x4 / 8x8 maps (mdm_gemm_can_fuse_gn_bwd says
+     * whether this descriptor qualifies): the contraction result is d(z), z = silu?(GroupNorm(x)); instead of storing
+     * it, the epilogue reads x, stats (mean, rstd per image and group), gamma, beta and writes dx into D0 (acc0 honoured),
+     * adds dgamma / dbeta, and optionally the column sums of dx (gnb_sum_img[n * gnb_sum_ld + c] = sum_p dx,
+     * gnb_sum_all[c] += sum_{n,p} dx) like mdm_groupnorm_bwd_sums.  NULL gnb_x = plain epilogue. */
+    const void* gnb_x; const float* gnb_stats; const float* gnb_gamma; const float* gnb_beta;
+    float* gnb_dgamma; float* gnb_dbeta; float* gnb_sum_img; float* gnb_sum_all;
+    int32_t gnb_G, gnb_silu, gnb_sum_ld, _p3;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
@@ -119,6 +128,9 @@ int mdm_gemm_discard_pending(void);
 /* What mdm_gemm would choose for this descriptor given unlimited workspace: the split count and the
  * workspace bytes it needs (0 when it would not use partial slabs).  No launch. */
 int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out);
+/* 1 if mdm_gemm would run this descriptor (a bf16 3x3 data gradient through the transposed filters) on the whole-image
+ * halo tiles AND groups of G channels are whole inside a 64-channel tile, i.e. the gnb_* epilogue may be used; else 0. */
+int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)

@@ -1212,6 +1212,134 @@ __device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, const
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// GroupNorm backward fused into the data-gradient epilogue of the conv that consumes the normalised tensor, for the
+// 64-pixel x 64-channel halo tiles of whole images (4x4 / 8x8 maps): the tile IS complete (image, group) blocks, so the
+// group sums stay inside the workgroup and d(z) never goes to memory.  512 threads = 64 pixels x 8 channel chunks.
+// Same arithmetic as gn_bwd_reg_kernel (norm.hip); d(z) enters in fp32 instead of bf16.
+// LDS: [0, 16K) the fp32 tile, [16K, 80K) column-sum scratch, then small arrays.
+// ----------------------------------------------------------------------------
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
+                                                  int lane, int t, f32x4 (&acc)[MI][NI]) {
+    constexpr int BM = 64, BN = 64, PITCH = BN * 4;
+    float* scratch = reinterpret_cast<float*>(lds + 16384);               // [32][512]
+    float* psum = reinterpret_cast<float*>(lds + 16384 + 65536);          // [256 columns][4 parts]
+    float* gs = psum + 1024;                                              // [4 images][16 groups][2]
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = row_w + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = col_w + j * 16 + 4 * (lane >> 4);
+            *reinterpret_cast<float4*>(lds + ml * PITCH + (((nl >> 2) ^ (ml & 7)) << 4)) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+    if (t < 128) gs[t] = 0.f;
+    __syncthreads();
+    const int C = d.N, G = d.gnb_G, cpg = C / G, P = d.OH * d.OW;          // P = 16 or 64 pixels per image
+    const int r = t >> 3, q = t & 7, il = r / P;
+    const int m = m0 + r, n = n0 + q * 8, img = m0 / P + il;
+    const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
+    const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
+    const float dz[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const float8 x8 = load8(reinterpret_cast<const bf16_t*>(d.gnb_x) + (int64_t)m * C + n);
+    const float xv[8] = {x8.lo.x, x8.lo.y, x8.lo.z, x8.lo.w, x8.hi.x, x8.hi.y, x8.hi.z, x8.hi.w};
+    const float4 g_lo = *reinterpret_cast<const float4*>(d.gnb_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnb_gamma + n + 4);
+    const float4 b_lo = *reinterpret_cast<const float4*>(d.gnb_beta + n), b_hi = *reinterpret_cast<const float4*>(d.gnb_beta + n + 4);
+    const float ga[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
+    const float be[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+    float rstd[8], xh[8], gz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + (n + e) / cpg) * 2);
+        rstd[e] = st.y;
+        xh[e] = (xv[e] - st.x) * st.y;
+        gz[e] = dz[e];
+        if (d.gnb_silu) gz[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
+        scratch[e * 512 + t] = gz[e] * ga[e];                             // a1: sum over the group of dy*gamma
+        scratch[(8 + e) * 512 + t] = gz[e] * ga[e] * xh[e];               // a2
+        scratch[(16 + e) * 512 + t] = gz[e] * xh[e];                      // dgamma
+        scratch[(24 + e) * 512 + t] = gz[e];                              // dbeta
+    }
+    __syncthreads();
+    // column sums over the pixels, in 4 parts of 16 rows (a part never straddles an image: P is 16 or 64)
+#pragma unroll
+    for (int it2 = 0; it2 < 2; ++it2) {
+        const int id = t + 512 * it2, col = id >> 2, part = id & 3;      // col = k * 8 + chunk
+        const float* src = scratch + (col >> 3) * 512 + (part * 16) * 8 + (col & 7);
+        float sum = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sum += src[rr * 8];
+        psum[id] = sum;
+    }
+    __syncthreads();
+    if (t < 128) {                       // dgamma / dbeta: one atomic per channel per workgroup
+        const int which = t >> 6, c = t & 63, col = ((16 + 8 * which + (c & 7)) << 3) + (c >> 3);
+        const float v = psum[col * 4] + psum[col * 4 + 1] + psum[col * 4 + 2] + psum[col * 4 + 3];
+        atomicAdd(which ? d.gnb_dbeta + n0 + c : d.gnb_dgamma + n0 + c, v);
+    }
+    {                                    // group sums per image: (image il2, channel c) -> gs[il2][group][0/1]
+        const int ppi = P >> 4;          // parts per image (1 or 4)
+        const int nimg = 64 / P;
+        if (t < nimg * 64) {
+            const int il2 = t >> 6, c = t & 63;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int col = ((8 * w + (c & 7)) << 3) + (c >> 3);
+                float v = 0.f;
+                for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
+                atomicAdd(&gs[(il2 * 16 + c / cpg) * 2 + w], v);
+            }
+        }
+    }
+    __syncthreads();
+    const float inv_cnt = 1.f / ((float)cpg * (float)P);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int gl = (q * 8 + e) / cpg;
+        const float k1 = rstd[e] * gs[(il * 16 + gl) * 2] * inv_cnt, k2 = rstd[e] * gs[(il * 16 + gl) * 2 + 1] * inv_cnt;
+        o[e] = rstd[e] * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
+    }
+    if (d.gnb_sum_img || d.gnb_sum_all) {                                  // uniform: column sums of dx (before accumulation)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) scratch[e * 512 + t] = o[e];
+    }
+    {
+        bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
+        float8 v = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+        if (d.acc0) {
+            const float8 old = load8(p);
+            v.lo.x += old.lo.x; v.lo.y += old.lo.y; v.lo.z += old.lo.z; v.lo.w += old.lo.w;
+            v.hi.x += old.hi.x; v.hi.y += old.hi.y; v.hi.z += old.hi.z; v.hi.w += old.hi.w;
+        }
+        store8(p, v);
+    }
+    if (d.gnb_sum_img || d.gnb_sum_all) {
+        __syncthreads();
+        if (t < 256) {
+            const int col = t >> 2, part = t & 3;                          // col = e * 8 + chunk
+            const float* src = scratch + (col >> 3) * 512 + (part * 16) * 8 + (col & 7);
+            float sum = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sum += src[rr * 8];
+            psum[t] = sum;
+        }
+        __syncthreads();
+        const int ppi = P >> 4, nimg = 64 / P;
+        if (t < nimg * 64) {
+            const int il2 = t >> 6, c = t & 63, col = ((c & 7) << 3) + (c >> 3);
+            float v = 0.f;
+            for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
+            if (d.gnb_sum_img) d.gnb_sum_img[(int64_t)(m0 / P + il2) * d.gnb_sum_ld + n0 + c] = v;      // this workgroup owns (image, channel)
+            if (d.gnb_sum_all) atomicAdd(d.gnb_sum_all + n0 + c, v);
+        }
+    }
+}
+
 #ifdef MDM_STAMP
 // debug build only (make EXTRA=-DMDM_STAMP): cycles per phase of the slab loop, summed over waves
 __device__ unsigned long long g_stamp_buf[4096 * 32];     // one 32-entry record per wave, plain stores
@@ -1899,7 +2027,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     wait_vmcnt<0>();
     MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
-    epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+    if constexpr (BM == 64 && BN == 64) {
+        if (d.gnb_x) epilogue_tile_gnb<MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
+        else epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+    } else {
+        epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+    }
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
@@ -2060,6 +2193,7 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
     const int NPA = halo_pieces(BM, d.OH, d.OW);
     int bytes = 2 * NPA * 1024 + NSB * TG * BN * 128 + 1024;
     if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
+    if (BM == 64 && d.gnb_x && bytes < 16384 + 65536 + 4096 + 512) bytes = 16384 + 65536 + 4096 + 512;   // fused GroupNorm backward
     MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
     static int configured = 0;
     if (configured < bytes) {
@@ -2131,6 +2265,9 @@ static int g_halo = []() { const char* e = getenv("MDM_HALO"); return (e && e[0]
 static int g_wgrad_lin = []() { const char* e = getenv("MDM_WGRAD_LIN"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
 
+}  // namespace mdm
+extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G);
+namespace mdm {
 static thread_local std::vector<ReduceSeg> g_pending;
 
 int flush_wgrad(hipStream_t s);
@@ -2206,6 +2343,9 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
     } else {
         d.ws = nullptr;
     }
+    if (d.gnb_x && !plan_splitk)
+        MDM_REQUIRE(mdm_gemm_can_fuse_gn_bwd(&d, d.gnb_G) == 1 && d.gnb_stats && d.gnb_gamma && d.gnb_beta && d.gnb_dgamma && d.gnb_dbeta,
+                    "gemm: gnb_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_bwd)");
     if (plan_splitk) {
         *plan_splitk = d.splitk;
         *plan_ws = (d.ws && d.splitk > 1) ? (tap_split ? (int64_t)d.splitk * d.M * d.N * 4 : slab * d.splitk) : 0;
@@ -2323,6 +2463,16 @@ extern "C" int mdm_gemm_discard_pending(void) {           // error recovery: for
     mdm::g_pending_wgrad.clear();
     mdm::g_pending.clear();
     return 0;
+}
+extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
+    if (!desc_host || G <= 0) return 0;
+    mdm_gemm_desc d = *desc_host;
+    if (d.N0 == 0) d.N0 = d.N;
+    if (!mdm::g_halo || !mdm::g_use_ring || !mdm::g_use_lin || mdm::g_halo_tg != 3) return 0;
+    if (!(d.transposed && d.N % G == 0 && d.N0 == d.N && d.C1 == 0 && !d.D1 && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f)) return 0;
+    const int cpg = d.N / G;
+    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
+    return mdm::halo_tile(d, mdm::g_big_min_tiles) == 64 ? 1 : 0;
 }
 extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
     if (!splitk_out || !ws_bytes_out) { mdm::set_error("gemm_plan: null output"); return -1; }

@@ -81,15 +81,35 @@ def conv_dgrad(dt, g: ConvGeom, dy, w, dst0, acc0, dst1=None, acc1=0):
               D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g))
 
 
-def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None):
+def _dgrad_t_fields(dt, g, dy, wT, dst0, acc0, dst1, acc1, ws):
+    return dict(dtype=dt, layout=0, M=g.N * g.VH * g.VW, N=g.Cin, K=g.taps * g.Cout,
+                conv=1, OH=g.VH, OW=g.VW, IH=g.OH, IW=g.OW, KH=g.KH, KW=g.KW, stride=g.stride,
+                pad_t=g.pad_t, pad_l=g.pad_l, transposed=1, ups=0, C0=g.Cout, C1=0, Ck=g.Cout,
+                src0=dy, src1=None, ld0=g.Cout, ld1=0, B=wT, ldb=g.Cout, wtap=g.Cout * g.Cin,
+                D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g),
+                ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
+
+
+def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None, gnb=None):
     """Same gradient as conv_dgrad but with per-tap TRANSPOSED filters wT[tap][Cin][Cout]: both operands
-    are k-contiguous (layout 0), the path the forward uses."""
-    _lib.gemm(dtype=dt, layout=0, M=g.N * g.VH * g.VW, N=g.Cin, K=g.taps * g.Cout,
-              conv=1, OH=g.VH, OW=g.VW, IH=g.OH, IW=g.OW, KH=g.KH, KW=g.KW, stride=g.stride,
-              pad_t=g.pad_t, pad_l=g.pad_l, transposed=1, ups=0, C0=g.Cout, C1=0, Ck=g.Cout,
-              src0=dy, src1=None, ld0=g.Cout, ld1=0, B=wT, ldb=g.Cout, wtap=g.Cout * g.Cin,
-              D0=dst0, ldd0=g.C0, D1=dst1, ldd1=g.C1, N0=g.C0, acc0=acc0, acc1=acc1, _flops=conv_flops(g),
-              ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
+    are k-contiguous (layout 0), the path the forward uses.  `gnb` (see conv_dgrad_t_can_fuse_gn_bwd): the conv's input
+    was z = silu?(GroupNorm(x)); dict(x, stats, gamma, beta, dgamma, dbeta, G, silu[, sum_img, sum_ld, sum_all]) makes
+    the epilogue run that GroupNorm's backward, so dst0 receives dx (not dz) and dgamma / dbeta are accumulated."""
+    f = _dgrad_t_fields(dt, g, dy, wT, dst0, acc0, dst1, acc1, ws)
+    if gnb is not None:
+        f.update(gnb_x=gnb["x"], gnb_stats=gnb["stats"], gnb_gamma=gnb["gamma"], gnb_beta=gnb["beta"],
+                 gnb_dgamma=gnb["dgamma"], gnb_dbeta=gnb["dbeta"], gnb_G=int(gnb.get("G", 32)), gnb_silu=int(bool(gnb["silu"])),
+                 gnb_sum_img=gnb.get("sum_img"), gnb_sum_ld=int(gnb.get("sum_ld", 0)), gnb_sum_all=gnb.get("sum_all"))
+    _lib.gemm(**f)
+
+
+def conv_dgrad_t_can_fuse_gn_bwd(dt, g: ConvGeom, G=32):
+    """True if conv_dgrad_t on this geometry runs on the whole-image halo tiles, so that `gnb` may be used."""
+    if g.C1 or g.ups:
+        return False
+    f = _dgrad_t_fields(dt, g, 16, 16, 16, 0, None, 0, None)
+    f.pop("_flops")
+    return bool(_lib.load().mdm_gemm_can_fuse_gn_bwd(_lib.C.byref(_lib._desc(f)), int(G)))
 
 
 def _wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer, defer_launch=False):

@@ -230,7 +230,23 @@ class _Conv:
             dgrad = lambda *a: ops.conv_dgrad_t(*a, ws=n.splitk_ws)     # small maps split the taps over the grid
         else:
             dgrad, wmat = ops.conv_dgrad, st.w(self.name + ".weight")
-        if g.ups:
+        nm = getattr(s0, "norm_spec", None)          # the GroupNorm that produced this conv's input (if any)
+        if (n.dt == BF16 and n.fuse_gn_bwd and nm is not None and nm.src1 is None and s1 is None and not g.ups and not fork
+                and ops.conv_dgrad_t_can_fuse_gn_bwd(n.dt, g)):
+            # 4x4 / 8x8 maps: the data gradient runs on whole-image tiles, so the GroupNorm backward is its epilogue --
+            # d(z) never goes to memory and the GroupNorm launch disappears (_Norm.bwd sees bwd_fused)
+            x = nm.src0
+            gx, ax = n.grad_for_write(x)
+            sums = {}
+            prod = getattr(nm, "producer", None)     # conv1 of a ResidualBlock: this dx is its complete dY
+            if prod is not None and ax == 0:
+                sums = dict(sum_img=n.dT_all[:, prod.fc_slot:], sum_ld=n.fc_total, sum_all=st.g(prod.name + ".bias"))
+                prod.sums_by_norm = True
+            ops.conv_dgrad_t(n.dt, g, dy, wmat, gx, ax, ws=n.splitk_ws,
+                             gnb=dict(x=x.data, stats=nm.stats, gamma=st.f(nm.name + ".weight"), beta=st.f(nm.name + ".bias"),
+                                      dgamma=st.g(nm.name + ".weight"), dbeta=st.g(nm.name + ".bias"), G=32, silu=nm.silu, **sums))
+            nm.bwd_fused = True
+        elif g.ups:
             tmp = n.scratch(g.N * g.VH * g.VW * g.Cin)
             dgrad(n.dt, g, dy, wmat, tmp, 0)
             g0, a0 = n.grad_for_write(s0)
@@ -262,6 +278,8 @@ class _Norm:
     def bwd(self):
         n, st = self.net, self.net.store
         s0, s1 = self.src0, self.src1
+        if getattr(self, "bwd_fused", False):       # done in the epilogue of the consuming conv's data gradient
+            return
         assert self.out.grad_written, self.name
         g0, a0 = n.grad_for_write(s0)
         g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
@@ -383,6 +401,7 @@ class UNet:
         self._scratch = None
         self._scratch_n = 0
         self.use_graph = use_graph
+        self.fuse_gn_bwd = os.environ.get("MDM_FUSE_GN_BWD", "1") != "0"
         self.concurrent_bwd = int(os.environ.get("MDM_CONCURRENT_BWD", "0"))    # 1: every conv, 2: only maps <= 8x8    # measured slower (10.96 vs 10.57 ms/step at cfg2)
         shared = store is not None
         self.store = store if shared else ParamStore()
@@ -449,6 +468,7 @@ class UNet:
         def norm(name, src0, src1, silu):
             out = self._act(name, src0.H, src0.W, src0.C + (src1.C if src1 else 0))
             self.specs.append(_Norm(self, name, src0, src1, out, silu))
+            out.norm_spec = self.specs[-1]
             return out
 
         def res(pre, x0, x1, Cout):                       # ResidualBlock (unet6.py:336-362)

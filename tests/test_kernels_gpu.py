@@ -414,3 +414,52 @@ def test_deferred_weight_gradients_match_immediate_ones():
     for a, b in zip(got, want):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
         assert float((b - 0.5).abs().max()) > 0.1                         # accumulated onto the initial value, and non-trivial
+
+
+@pytest.mark.parametrize("case", [(8, 8, 256, 256, True, False), (16, 4, 128, 256, True, True), (4, 8, 128, 64, False, False),
+                                  (8, 8, 512, 256, True, True)])
+def test_groupnorm_backward_fused_into_the_data_gradient(case):
+    """4x4 / 8x8 maps: z = silu?(GroupNorm(x)) feeds a 3x3 conv; the conv's data gradient runs the GroupNorm backward in
+    its epilogue (gnb_*): dx, dgamma, dbeta and the optional column sums against torch autograd."""
+    from mdm import ops
+    dt = "bf16"
+    N, H, C, Cout, silu, with_sums = case
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C)
+    x = _q(torch.randn(N, C, H, H, generator=g) * 1.2 + 0.3, dt).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    w = _q(torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5), dt)
+    z = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    if silu:
+        z = F.silu(z)
+    y = F.conv2d(z, w, None, padding=1)
+    gy = _q(torch.randn(y.shape, generator=g), dt)
+    y.backward(gy)
+    dev = _dev()
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
+    assert ops.conv_dgrad_t_can_fuse_gn_bwd(1, geom)
+    xh = _up(_nhwc(x.detach()), dt)
+    zb = torch.empty_like(xh); stats = torch.empty(N, 32, 2, device=dev)
+    ws = torch.empty(N * (64 * 32 + 4 * C), device=dev)
+    gd, bd = gamma.detach().to(dev), beta.detach().to(dev)
+    ops.groupnorm_fwd(1, xh.view(N, H * H, C), C, None, 0, N, H * H, gd, bd, silu, zb.view(N, H * H, C), stats, ws)
+    wT = _up(_w_tap(w).transpose(1, 2).contiguous(), dt)
+    base = _q(torch.randn(N, C, H, H, generator=g), dt)
+    dx = _up(_nhwc(base), dt).clone()                      # dx is ACCUMULATED onto an existing gradient when no sums are asked
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    gnb = dict(x=xh, stats=stats, gamma=gd, beta=bd, dgamma=dg, dbeta=db, G=32, silu=silu)
+    acc = 1
+    if with_sums:
+        per = torch.full((N, C + 8), 3.0, device=dev); tot = torch.zeros(C, device=dev)
+        gnb.update(sum_img=per[:, 8:], sum_ld=C + 8, sum_all=tot)
+        acc = 0
+    ops.conv_dgrad_t(1, geom, _up(_nhwc(gy), dt), wT, dx, acc, gnb=gnb)
+    torch.cuda.synchronize()
+    want = _nhwc(x.grad + (base if acc else 0))
+    assert _relerr(dx, want) < _tol(dt, 1.5)
+    assert _relerr(dg, gamma.grad) < _tol(dt) and _relerr(db, beta.grad) < _tol(dt)
+    if with_sums:
+        gx = _nhwc(x.grad)
+        scale = float(gx.abs().sum((1, 2)).mean())
+        assert float((per[:, 8:].cpu() - gx.sum((1, 2))).abs().max()) < _tol(dt, 0.5) * scale and float((per[:, :8] - 3.0).abs().sum()) == 0
+        assert float((tot.cpu() - gx.sum((0, 1, 2))).abs().max()) < _tol(dt, 0.5) * scale * N

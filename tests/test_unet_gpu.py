@@ -100,9 +100,13 @@ CFG4_TINY = dict(in_channels=4, hid_channels=32, out_channels=4, ch_multipliers=
                  apply_attn=[True, True, True])          # cfg4: C=4, attention at every level (L = 1024, 256, 64)
 CFG3_TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
                  apply_attn=[False, False, True, False])  # cfg3: the unet6 preset's topology at 64x64, narrow
+CFG_WIDE = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2], num_res_blocks=1,
+                apply_attn=[False, True, False])         # the preset's widths on 16x16: 8x8 and 4x4 levels with >= 4 channels per
+                                                         # group -> whole-image halo tiles, GroupNorm backward fused into the data gradient
 
 
-@pytest.mark.parametrize("name,cfg,hw,n", [("cfg4_attn_everywhere_C4", CFG4_TINY, 32, 2), ("cfg3_64x64", CFG3_TINY, 64, 2)])
+@pytest.mark.parametrize("name,cfg,hw,n", [("cfg4_attn_everywhere_C4", CFG4_TINY, 32, 2), ("cfg3_64x64", CFG3_TINY, 64, 2),
+                                           ("preset_widths_16x16", CFG_WIDE, 16, 4)])
 @pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
 def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, tol_g):
     from mdm import ops
@@ -112,7 +116,7 @@ def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, t
     g = torch.Generator().manual_seed(13)
     c = cfg["in_channels"]
     x = torch.rand(n, c, hw, hw, generator=g) * 2 - 1
-    t = torch.tensor([5.0, 321.0][:n])
+    t = torch.tensor([5.0, 321.0, 77.0, 950.0][:n])
     gy = torch.randn(n, c, hw, hw, generator=g)
     net = U.UNet(cfg, N=n, H=hw, W=hw, dtype=dt, params=p)
     y = net(x, t).sample
