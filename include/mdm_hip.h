@@ -114,6 +114,12 @@ typedef struct mdm_gemm_desc {
     const void* gnb_x; const float* gnb_stats; const float* gnb_gamma; const float* gnb_beta;
     float* gnb_dgamma; float* gnb_dbeta; float* gnb_sum_img; float* gnb_sum_all;
     int32_t gnb_G, gnb_silu, gnb_sum_ld, _p3;
+    /* Fused GroupNorm FORWARD in the epilogue of the conv that PRODUCES the tensor, same tiles (mdm_gemm_can_fuse_gn_fwd):
+     * after the usual epilogue has stored y (bf16), the workgroup normalises the values it just rounded:
+     * gnf_out = silu?(GroupNorm_G(y) * gamma + beta) (bf16, same shape as y), gnf_stats[n][g] = (mean, rstd).
+     * NULL gnf_out = plain epilogue. */
+    void* gnf_out; const float* gnf_gamma; const float* gnf_beta; float* gnf_stats;
+    int32_t gnf_G, gnf_silu; float gnf_eps; int32_t _p4;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
@@ -131,6 +137,8 @@ int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_b
 /* 1 if mdm_gemm would run this descriptor (a bf16 3x3 data gradient through the transposed filters) on the whole-image
  * halo tiles AND groups of G channels are whole inside a 64-channel tile, i.e. the gnb_* epilogue may be used; else 0. */
 int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G);
+/* the same question for the gnf_* epilogue of a bf16 3x3 forward convolution */
+int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)

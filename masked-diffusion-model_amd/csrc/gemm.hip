@@ -1340,6 +1340,113 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// GroupNorm forward fused into the epilogue of the conv that PRODUCES the tensor (same 64-pixel x 64-channel tiles of
+// whole images): the usual epilogue (scale, bias, time-embedding row, residual, bf16 rounding, store y), then
+// statistics over the ROUNDED values exactly as a separate GroupNorm launch would see them -- two passes (mean, then
+// centred squares: exact for constant maps like the pivot-shifted sums of norm.hip) -- and z = silu?(y_hat*gamma+beta).
+// ----------------------------------------------------------------------------
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
+                                                  int lane, int t, f32x4 (&acc)[MI][NI]) {
+    constexpr int BN = 64, PITCH = BN * 4;
+    float* scratch = reinterpret_cast<float*>(lds + 16384);               // [8][512]
+    float* psum = reinterpret_cast<float*>(lds + 16384 + 16384);          // [64 columns][4 parts]
+    float* gs = psum + 256;                                               // [4 images][16 groups]: sum, then centred squares
+    float* gm = gs + 64;                                                  // mean
+    float* gr = gm + 64;                                                  // rstd
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = row_w + i * 16 + (lane & 15), mrow = m0 + ml;
+        const float* rv = (d.rowvec && mrow < d.M) ? d.rowvec + (int64_t)(mrow / d.rows_per_img) * d.rv_ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int nl = col_w + j * 16 + 4 * (lane >> 4), ncol = n0 + nl;
+            float4 v = make_float4(acc[i][j][0] * d.alpha, acc[i][j][1] * d.alpha, acc[i][j][2] * d.alpha, acc[i][j][3] * d.alpha);
+            if (d.bias) { float4 b = *reinterpret_cast<const float4*>(d.bias + ncol); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (rv) { float4 b = *reinterpret_cast<const float4*>(rv + ncol); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            *reinterpret_cast<float4*>(lds + ml * PITCH + (((nl >> 2) ^ (ml & 7)) << 4)) = v;
+        }
+    }
+    if (t < 64) gs[t] = 0.f;
+    __syncthreads();
+    const int C = d.N, G = d.gnf_G, cpg = C / G, P = d.OH * d.OW;
+    const int r = t >> 3, q = t & 7, il = r / P;
+    const int m = m0 + r, n = n0 + q * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
+    const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
+    float8 v = {lo, hi};
+    if (d.resid) {
+        const float8 b = load8(reinterpret_cast<const bf16_t*>(d.resid) + (int64_t)m * d.ldr + n);
+        v.lo.x += b.lo.x; v.lo.y += b.lo.y; v.lo.z += b.lo.z; v.lo.w += b.lo.w;
+        v.hi.x += b.hi.x; v.hi.y += b.hi.y; v.hi.z += b.hi.z; v.hi.w += b.hi.w;
+    }
+    bf16_t* yp = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
+    store8(yp, v);
+    // the values as GroupNorm reads them back: rounded to bf16
+    const float vv[8] = {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w};
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = bf2f(f2bf(vv[e]));
+    const int ppi = P >> 4, nimg = 64 / P;
+    const float inv_cnt = 1.f / ((float)cpg * (float)P);
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float c0 = pass ? y[e] - mean[e] : y[e]; scratch[e * 512 + t] = pass ? c0 * c0 : c0; }
+        __syncthreads();
+        if (t < 256) {
+            const int col = t >> 2, part = t & 3;                          // col = e * 8 + chunk
+            const float* src = scratch + (col >> 3) * 512 + (part * 16) * 8 + (col & 7);
+            float sum = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sum += src[rr * 8];
+            psum[t] = sum;
+        }
+        __syncthreads();
+        if (t < nimg * 64) {
+            const int il2 = t >> 6, c = t & 63, col = ((c & 7) << 3) + (c >> 3);
+            float s2 = 0.f;
+            for (int pp = 0; pp < ppi; ++pp) s2 += psum[col * 4 + il2 * ppi + pp];
+            atomicAdd(&gs[il2 * 16 + c / cpg], s2);
+        }
+        __syncthreads();
+        if (t < 64) {
+            if (pass == 0) gm[t] = gs[t] * inv_cnt; else gr[t] = rsqrtf(gs[t] * inv_cnt + d.gnf_eps);
+        }
+        __syncthreads();
+        if (pass == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mean[e] = gm[il * 16 + (q * 8 + e) / cpg];
+            if (t < 64) gs[t] = 0.f;
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rstd[e] = gr[il * 16 + (q * 8 + e) / cpg];
+        }
+    }
+    const float4 g_lo = *reinterpret_cast<const float4*>(d.gnf_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnf_gamma + n + 4);
+    const float4 b_lo = *reinterpret_cast<const float4*>(d.gnf_beta + n), b_hi = *reinterpret_cast<const float4*>(d.gnf_beta + n + 4);
+    const float ga[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
+    const float be[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] = fmaf((y[e] - mean[e]) * rstd[e], ga[e], be[e]);
+        if (d.gnf_silu) o[e] = silu_f(o[e]);
+    }
+    const float8 zo = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+    store8(reinterpret_cast<bf16_t*>(d.gnf_out) + (int64_t)m * C + n, zo);
+    const int ngt = 64 / cpg;                                              // groups inside this 64-channel tile
+    if (t < nimg * ngt) {
+        const int il2 = t / ngt, gl = t - il2 * ngt;
+        float* sp = d.gnf_stats + ((int64_t)(m0 / P + il2) * G + n0 / cpg + gl) * 2;
+        sp[0] = gm[il2 * 16 + gl]; sp[1] = gr[il2 * 16 + gl];
+    }
+}
+
 #ifdef MDM_STAMP
 // debug build only (make EXTRA=-DMDM_STAMP): cycles per phase of the slab loop, summed over waves
 __device__ unsigned long long g_stamp_buf[4096 * 32];     // one 32-entry record per wave, plain stores
@@ -2029,6 +2136,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     __syncthreads();
     if constexpr (BM == 64 && BN == 64) {
         if (d.gnb_x) epilogue_tile_gnb<MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
+        else if (d.gnf_out) epilogue_tile_gnf<MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
         else epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
         epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
@@ -2267,6 +2375,7 @@ static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e
 
 }  // namespace mdm
 extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G);
+extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G);
 namespace mdm {
 static thread_local std::vector<ReduceSeg> g_pending;
 
@@ -2346,6 +2455,9 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
     if (d.gnb_x && !plan_splitk)
         MDM_REQUIRE(mdm_gemm_can_fuse_gn_bwd(&d, d.gnb_G) == 1 && d.gnb_stats && d.gnb_gamma && d.gnb_beta && d.gnb_dgamma && d.gnb_dbeta,
                     "gemm: gnb_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_bwd)");
+    if (d.gnf_out && !plan_splitk)
+        MDM_REQUIRE(mdm_gemm_can_fuse_gn_fwd(&d, d.gnf_G) == 1 && d.gnf_gamma && d.gnf_beta && d.gnf_stats,
+                    "gemm: gnf_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_fwd)");
     if (plan_splitk) {
         *plan_splitk = d.splitk;
         *plan_ws = (d.ws && d.splitk > 1) ? (tap_split ? (int64_t)d.splitk * d.M * d.N * 4 : slab * d.splitk) : 0;
@@ -2470,6 +2582,16 @@ extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
     if (d.N0 == 0) d.N0 = d.N;
     if (!mdm::g_halo || !mdm::g_use_ring || !mdm::g_use_lin || mdm::g_halo_tg != 3) return 0;
     if (!(d.transposed && d.N % G == 0 && d.N0 == d.N && d.C1 == 0 && !d.D1 && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f)) return 0;
+    const int cpg = d.N / G;
+    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
+    return mdm::halo_tile(d, mdm::g_big_min_tiles) == 64 ? 1 : 0;
+}
+extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G) {
+    if (!desc_host || G <= 0) return 0;
+    mdm_gemm_desc d = *desc_host;
+    if (d.N0 == 0) d.N0 = d.N;
+    if (!mdm::g_halo || !mdm::g_use_ring || !mdm::g_use_lin || mdm::g_halo_tg != 3) return 0;
+    if (!(!d.transposed && d.N % G == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.acc0 && d.ldd0 == d.N)) return 0;
     const int cpg = d.N / G;
     if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
     return mdm::halo_tile(d, mdm::g_big_min_tiles) == 64 ? 1 : 0;

@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp), ("defer_reduce", i32), ("defer_launch", i32),
         ("gnb_x", vp), ("gnb_stats", vp), ("gnb_gamma", vp), ("gnb_beta", vp), ("gnb_dgamma", vp), ("gnb_dbeta", vp),
         ("gnb_sum_img", vp), ("gnb_sum_all", vp), ("gnb_G", i32), ("gnb_silu", i32), ("gnb_sum_ld", i32), ("_p3", i32),
+        ("gnf_out", vp), ("gnf_gamma", vp), ("gnf_beta", vp), ("gnf_stats", vp), ("gnf_G", i32), ("gnf_silu", i32), ("gnf_eps", f32), ("_p4", i32),
     ]
 
 
@@ -45,6 +46,7 @@ _PROTOS = {
     "mdm_gemm_discard_pending": ([], i32),
     "mdm_gemm_plan": ([C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i64)], i32),
     "mdm_gemm_can_fuse_gn_bwd": ([C.POINTER(GemmDesc), i32], i32),
+    "mdm_gemm_can_fuse_gn_fwd": ([C.POINTER(GemmDesc), i32], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], i32),

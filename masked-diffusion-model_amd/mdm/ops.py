@@ -61,15 +61,34 @@ def conv_flops(g: ConvGeom):
     return 2.0 * g.N * g.OH * g.OW * g.Cout * g.Cin * g.taps
 
 
-def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None):
-    """out[N,OH,OW,Cout] = conv(concat(src0,src1), w[tap][Cout][Cin]) + bias + rowvec[n] + resid."""
-    _lib.gemm(dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
+def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None, gnf=None):
+    """out[N,OH,OW,Cout] = conv(concat(src0,src1), w[tap][Cout][Cin]) + bias + rowvec[n] + resid.
+    Returns the descriptor.  `gnf` = dict(out, gamma, beta, stats, G, silu, eps): also the GroupNorm of the result in the
+    same launch (only where conv_fwd_can_fuse_gn says so); `fuse_gn_fwd(desc, ...)` sets it on a RECORDED call afterwards."""
+    extra = {} if gnf is None else _gnf_fields(gnf)
+    return _lib.gemm(**extra, dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
               conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
               pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
               src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, B=w, ldb=g.Cin, wtap=g.Cout * g.Cin,
               D0=out, ldd0=g.Cout, N0=g.Cout, out_f32=out_f32, bias=bias, rowvec=rowvec, rv_ld=rv_ld,
               rows_per_img=g.OH * g.OW, resid=resid, ldr=g.Cout, _flops=conv_flops(g),
               ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
+
+
+def _gnf_fields(gnf):
+    return dict(gnf_out=gnf["out"], gnf_gamma=gnf["gamma"], gnf_beta=gnf["beta"], gnf_stats=gnf["stats"], gnf_G=int(gnf.get("G", 32)),
+                gnf_silu=int(bool(gnf["silu"])), gnf_eps=float(gnf.get("eps", 1e-6)))
+
+
+def conv_fwd_can_fuse_gn(desc, G=32):
+    """True if the forward conv described by `desc` (as returned by conv_fwd) may carry the gnf_* epilogue."""
+    return bool(_lib.load().mdm_gemm_can_fuse_gn_fwd(_lib.C.byref(desc), int(G)))
+
+
+def fuse_gn_fwd(desc, gnf):
+    """Attach the GroupNorm-forward epilogue to an already RECORDED conv_fwd call (its descriptor is replayed by reference)."""
+    for k, v in _gnf_fields(gnf).items():
+        setattr(desc, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
 
 
 def conv_dgrad(dt, g: ConvGeom, dy, w, dst0, acc0, dst1=None, acc1=0):

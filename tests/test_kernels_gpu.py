@@ -463,3 +463,35 @@ def test_groupnorm_backward_fused_into_the_data_gradient(case):
         scale = float(gx.abs().sum((1, 2)).mean())
         assert float((per[:, 8:].cpu() - gx.sum((1, 2))).abs().max()) < _tol(dt, 0.5) * scale and float((per[:, :8] - 3.0).abs().sum()) == 0
         assert float((tot.cpu() - gx.sum((0, 1, 2))).abs().max()) < _tol(dt, 0.5) * scale * N
+
+
+@pytest.mark.parametrize("case", [(8, 8, 128, 256, True), (16, 4, 256, 128, True), (4, 8, 64, 512, False)])
+def test_groupnorm_forward_fused_into_the_producing_conv(case):
+    """4x4 / 8x8 maps: the conv's epilogue (bias + time-embedding row + residual, bf16 store) also writes
+    silu?(GroupNorm(y)) and the (mean, rstd) statistics (gnf_*)."""
+    from mdm import ops
+    dt = "bf16"
+    N, H, C, Cout, silu = case
+    g = torch.Generator().manual_seed(N * 100 + H + Cout)
+    x = _q(torch.randn(N, C, H, H, generator=g), dt)
+    w = _q(torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5), dt)
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(N, Cout, generator=g)
+    res = _q(torch.randn(N, Cout, H, H, generator=g), dt)
+    gamma = 1 + 0.2 * torch.randn(Cout, generator=g)
+    beta = 0.1 * torch.randn(Cout, generator=g)
+    y = _q(F.conv2d(x, w, b, padding=1) + rv[:, :, None, None] + res, dt)          # what a separate GroupNorm launch would read
+    z = F.group_norm(y, 32, gamma, beta, eps=1e-6)
+    if silu:
+        z = F.silu(z)
+    dev = _dev()
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
+    out = torch.empty(N, H, H, Cout, device=dev, dtype=torch.bfloat16)
+    zo = torch.empty_like(out); stats = torch.full((N, 32, 2), float("nan"), device=dev)
+    ops.conv_fwd(1, geom, _up(_nhwc(x), dt), None, _up(_w_tap(w), dt), b.to(dev), out, rowvec=rv.to(dev), rv_ld=Cout,
+                 resid=_up(_nhwc(res), dt), gnf=dict(out=zo, gamma=gamma.to(dev), beta=beta.to(dev), stats=stats, G=32, silu=silu))
+    torch.cuda.synchronize()
+    assert _relerr(out, _nhwc(y)) < _tol(dt)
+    assert _relerr(zo, _nhwc(z)) < _tol(dt)
+    yg = y.reshape(N, 32, -1)
+    assert _relerr(stats[..., 0], yg.mean(-1)) < 2e-2 and _relerr(stats[..., 1], 1.0 / torch.sqrt(yg.var(-1, unbiased=False) + 1e-6)) < 2e-2
