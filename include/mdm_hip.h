@@ -273,6 +273,8 @@ int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  * `tiles` (device, int64 x5 per tile: element offset of one tap's [Cout][Cin] matrix, Cout, Cin, row0, col0)
  * write PT[off + c*Cout + r] = bf16(P[off + r*Cin + c]). */
 int mdm_transpose_shadow(const float* P, void* PT, const int64_t* tiles, int ntiles, void* stream);
+/* the same from the bf16 shadow Pb (element offsets identical): PT[off + c*Cout + r] = Pb[off + r*Cin + c] */
+int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, int ntiles, void* stream);
 int mdm_fill_f32(float* p, float v, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------- *

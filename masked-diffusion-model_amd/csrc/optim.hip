@@ -83,6 +83,26 @@ __global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* P, b
     }
 }
 
+// the same transposition from the bf16 shadow (already rounded by the optimizer kernel): a third less traffic
+__global__ __launch_bounds__(256) void transpose_shadow_bf16_kernel(const bf16_t* Pb, bf16_t* PT, const int64_t* tiles, int ntiles) {
+    __shared__ bf16_t tile[32][34];
+    const int64_t* e = tiles + (int64_t)blockIdx.x * 5;
+    const int64_t off = e[0];
+    const int Cout = (int)e[1], Cin = (int)e[2], r0 = (int)e[3], c0 = (int)e[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < Cout && c < Cin) ? Pb[off + (int64_t)r * Cin + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;                        // write PT[c][r]
+        if (c < Cin && r < Cout) PT[off + (int64_t)c * Cout + r] = tile[tx][ty + 8 * i];
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
 }
@@ -117,6 +137,11 @@ extern "C" int mdm_transpose_shadow(const float* P, void* PT, const int64_t* til
     MDM_REQUIRE(P && PT && tiles && ntiles > 0, "transpose_shadow: bad arguments");
     hipLaunchKernelGGL(transpose_shadow_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, P, (bf16_t*)PT, tiles, ntiles);
     return launch_status("transpose_shadow");
+}
+extern "C" int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, int ntiles, void* stream) {
+    MDM_REQUIRE(Pb && PT && tiles && ntiles > 0, "transpose_shadow_bf16: bad arguments");
+    hipLaunchKernelGGL(transpose_shadow_bf16_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Pb, (bf16_t*)PT, tiles, ntiles);
+    return launch_status("transpose_shadow_bf16");
 }
 extern "C" int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);

@@ -114,7 +114,8 @@ class ParamStore:
 
     def emit_transposed_shadow(self):
         if self.PbT is not None:
-            _lib.call("mdm_transpose_shadow", _lib.ptr(self.P), _lib.ptr(self.PbT), _lib.ptr(self.tiles),
+            # from the bf16 shadow the optimizer (or sync_shadow's cast) has just written: a third less traffic than from P
+            _lib.call("mdm_transpose_shadow_bf16", _lib.ptr(self.Pb), _lib.ptr(self.PbT), _lib.ptr(self.tiles),
                       int(self.tiles.shape[0]), _lib.stream())
 
     def sync_shadow(self):
