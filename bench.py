@@ -20,8 +20,15 @@ Extra objects in that line:
   step_hbm     north_star's whole-step figure: algorithmic bytes (SURVEY 8(d) counting rule) /
                (step time x 8 TB/s);
   cpu_baseline the CPU oracle (own-words port of the reference trainer, oracle/) timed on this box's
-               host cores on a bounded sample (rank 0, N=1 only);
-  sampler      wall-clock of a 1000-step reverse sampling run (sample_num=100, history off; N=1 only).
+               host cores on a bounded sample: 2 warm-up + median of 10 train steps, and a bounded sample of
+               the reverse sampler (per-step time, scaled to 1000 steps x sample_num and said so) (rank 0, N=1 only);
+  sampler      wall-clock of a 1000-step reverse sampling run (sample_num=100, history off; N=1 only), timed in
+               fp32 AND bf16, each with `rel_l2_vs_oracle` measured on a bounded parity sample (same weights and
+               host-replayed draws through the CPU oracle in the cpu_baseline child); the headline entry is the
+               dtype that meets north_star's 1e-3.
+
+`--gpus N` without torchrun's environment starts the N ranks itself (child `python -m torch.distributed.run`,
+before this process touches the GPU) and relays the JSON line; a line whose n_gpus != --gpus is never printed.
 """
 from __future__ import annotations
 
@@ -65,11 +72,49 @@ def make_args(**kw):
     return a
 
 
-def cpu_baseline(n_steps=3):
-    """Time the CPU oracle's train step on the same workload shape (fp32, all host cores)."""
+PARITY_N, PARITY_STRIDE, PARITY_SEED = 4, 50, 4321      # the sampler parity sample: 4 images, every 50th of the 1000 timesteps
+
+
+def parity_params(shapes, seed=77):
+    """Non-degenerate weights for the sampler parity sample (the fresh-init model predicts ~0: its last conv is
+    the reference's 1e-5 'zero' init, SURVEY D13 -- useless for an error measurement).  Keys are visited in
+    sorted order so the GPU parent and the CPU child draw the same tensors from the same generator."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        if len(shp) == 1:
+            out[k] = 1.0 + 0.1 * torch.randn(shp, generator=g) if k.endswith("weight") else 0.05 * torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            out[k] = torch.randn(shp, generator=g) / math.sqrt(fan_in)
+    return out
+
+
+def _seed_host(s):
+    import random
+
+    import numpy as np
+    torch.manual_seed(s); np.random.seed(s); random.seed(s)      # main_train_masked.py:441-445
+
+
+def parity_args():
+    return make_args(rng_mode="replay", sample_num=PARITY_N, sample_latent_shape="uniform", sample_history=False)
+
+
+def cpu_baseline(n_steps=10, n_warm=2, parity_file=None):
+    """CPU child: time the oracle's train step (and a bounded sample of its reverse sampler) on the same
+    workload shape (fp32, the box's host cores); check the GPU sampler's parity sample against the oracle."""
+    import statistics
+
+    import numpy as np
+    from oracle.sampler_ref import SamplerRef
     from oracle.scheduler_ref import SchedulerRef
     from oracle.trainer_ref import train_step_ref
-    from oracle.unet_ref import UNetRef, unet6_config
+    from oracle.unet_ref import UNetRef, param_shapes, unet6_config
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -79,7 +124,8 @@ def cpu_baseline(n_steps=3):
     torch.set_num_threads(cores)
     a = make_args(rng_mode="replay")
     torch.manual_seed(0)
-    model = UNetRef(unet6_config(32), seed=0)
+    cfg = unet6_config(32)
+    model = UNetRef(cfg, seed=0)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     ema = [p.detach().clone() for p in model.parameters()]
     s = SchedulerRef(a)
@@ -87,15 +133,40 @@ def cpu_baseline(n_steps=3):
     used = s.get_timesteps_epoch(0, 1)
     x0 = torch.rand(32, 3, 32, 32) * 2 - 1
     log(f"cpu baseline: oracle model built, {cores} threads")
-    train_step_ref(model, opt, s, a, x0, used, s.rng, ema_params=ema, ema_step=0)          # warm-up
-    log("cpu baseline: warm-up step done")
-    t0 = time.perf_counter()
+    for k in range(n_warm):
+        train_step_ref(model, opt, s, a, x0, used, s.rng, ema_params=ema, ema_step=k)
+    log(f"cpu baseline: {n_warm} warm-up steps done")
+    times = []
     for k in range(n_steps):
-        train_step_ref(model, opt, s, a, x0, used, s.rng, ema_params=ema, ema_step=k + 1)
-        log(f"cpu baseline: step {k + 1}/{n_steps}")
-    dt = time.perf_counter() - t0
-    return {"value": round(32 * n_steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n_steps} optimisation steps of 32x3x32x32 after 1 warm-up step (oracle/trainer_ref.py, fp32)"}
+        t0 = time.perf_counter()
+        train_step_ref(model, opt, s, a, x0, used, s.rng, ema_params=ema, ema_step=n_warm + k)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    log(f"cpu baseline: {n_steps} timed steps, median {med:.3f}s (min {min(times):.3f}, max {max(times):.3f})")
+    out = {"value": round(32 / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"median of {n_steps} optimisation steps of 32x3x32x32 after {n_warm} warm-up steps "
+                     f"(oracle/trainer_ref.py, fp32); step times min/median/max {min(times):.3f}/{med:.3f}/{max(times):.3f} s"}
+    # ---- the reverse sampler on the CPU: the parity sample's loop (PARITY_N images, every PARITY_STRIDE-th timestep)
+    pa = parity_args()
+    ps = SchedulerRef(pa)
+    ps.update_ddpm_num_steps(1000)
+    ts = ps.get_timesteps_epoch(0, 1)[PARITY_STRIDE - 1::PARITY_STRIDE]
+    pm = UNetRef(cfg, parity_params(param_shapes(cfg)))
+    _seed_host(PARITY_SEED)
+    t0 = time.perf_counter()
+    want, _ = SamplerRef(None, pa, ps, [None] * 3).sample(pm, ts)
+    sec = time.perf_counter() - t0
+    per_img_step = sec / (len(ts) * PARITY_N)
+    out["sampler"] = {"seconds_per_reverse_step_per_image": round(per_img_step, 5), "cores": cores,
+                      "estimate_1000_steps_x100_seconds": round(per_img_step * 1000 * 100, 1),
+                      "sample": f"{len(ts)} reverse steps x {PARITY_N} images timed ({sec:.2f} s, oracle/sampler_ref.py fp32, history on); "
+                                "the 1000-step x sample_num=100 figure is that per-step-per-image time x 1e5 (an estimate, not a run)"}
+    log(f"cpu baseline: sampler sample {sec:.2f}s")
+    if parity_file and os.path.exists(parity_file):
+        z = np.load(parity_file)
+        w = want.double().numpy()
+        out["sampler_parity"] = {k: float(np.linalg.norm(z[k].astype(np.float64) - w) / np.linalg.norm(w)) for k in z.files}
+    return out
 
 
 def main():
@@ -110,10 +181,22 @@ def main():
     ap.add_argument("--sampler-steps", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
     opt_ = ap.parse_args()
     if opt_.cpu_baseline_only:           # child process of the cpu_baseline leg: CPU only, never touches the GPU
-        print(json.dumps(cpu_baseline()))
+        print(json.dumps(cpu_baseline(parity_file=opt_.parity_file)))
         return
+    if "WORLD_SIZE" not in os.environ and opt_.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks ourselves, one per GPU, BEFORE anything here touches the GPU
+        # (a process that has initialised HIP must not be replaced or forked into ranks), and relay their output.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt_.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     import mdm
     from mdm import _lib
@@ -123,6 +206,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != opt_.gpus:
+        raise SystemExit(f"bench.py: --gpus {opt_.gpus} but WORLD_SIZE={world}: refusing to print a line for another job size")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
     # (MDM_FORCE_DEVICE / MDM_DIST_BACKEND exist so the multi-rank path can be rehearsed on a 1-GPU box: two
@@ -210,41 +295,76 @@ def main():
         peak = PEAK_BF16_TFLOPS if dt == mdm.BF16 else 157.3
         # HBM bytes per launch of this kernel family from PMC counters: collected out of band by
         # scripts/pmc_traffic.sh (rocprofv3 cannot run inside the timed process) and committed under profiles/
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = round(json.load(fh)["hbm_bytes_per_launch"])
-        except Exception:
-            pass
+        traffic = mfma_busy = pmc_src = None
+        for fn in ("r02_pmc.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                    pj = json.load(fh)
+                traffic, mfma_busy, pmc_src = round(pj["hbm_bytes_per_launch"]), pj.get("mfma_busy"), "profiles/" + fn
+                break
+            except Exception:
+                pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "mfma_busy": mfma_busy, "pmc_source": pmc_src,
                     "launches_per_step": n_launch // reps, "flops_per_step": tot_fl / reps,
                     "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "kernel_ms_per_step": round(tot_ms / reps, 3),
                     "event_pair_us": round(1e3 * pair_ms, 2)}
         P = model.num_parameters()
-        a_out = model.census()
-        bytes_step = (38 + 8) * P + 10 * a_out               # 38 B/param (+8 EMA) + 5 passes x 2 B x A_out
-        step_hbm = {"algorithmic_bytes": bytes_step, "a_out": a_out, "params": P,
-                    "achieved_GBs": round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1), "peak_GBs": PEAK_HBM_GBS,
-                    "frac": round(bytes_step / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        # 38 B/param (+8 EMA) + 5 passes x 2 B x A_out.  A_out is FROZEN in BASELINE.md at SURVEY's probed
+        # figure (386.8 M leaf-op output elements at cfg2, N=32: what `frac` uses, scaled with N); the builder's own
+        # census (residual / time-embedding adds, concats, upsample and SamePad copies counted as leaf outputs too) is
+        # reported next to it.
+        a_survey = int(386.8e6 * N / 32)
+        a_census = model.census()
+        b_survey, b_census = (38 + 8) * P + 10 * a_survey, (38 + 8) * P + 10 * a_census
+        gbs = lambda b: b / (ms_per_step * 1e-3) / 1e9
+        step_hbm = {"algorithmic_bytes": b_survey, "a_out": a_survey, "params": P,
+                    "achieved_GBs": round(gbs(b_survey), 1), "peak_GBs": PEAK_HBM_GBS, "frac": round(gbs(b_survey) / PEAK_HBM_GBS, 4),
+                    "census": {"a_out": a_census, "algorithmic_bytes": b_census, "frac": round(gbs(b_census) / PEAK_HBM_GBS, 4)},
+                    "flops_per_step": 34.87e9 * N, "tflops": round(34.87e9 * N / (ms_per_step * 1e-3) / 1e12, 1)}
 
-    # ---- 1k-step sampler wall-clock (single GPU only: samples are independent, no collective)
+    # ---- 1k-step sampler wall-clock (single GPU: samples are independent, no collective; N>1 shards sample_num)
     sampler = None
+    parity_file = None
     if rank == 0 and world == 1 and not opt_.no_sampler:
-        net = model.with_batch(args.sample_num).eval()
-        smp = mdm.Sampler(None, args, sched, [None] * 3)
-        log("sampler plan built")
-        smp.sample(net, used[:3])                            # warm-up / graph capture
-        torch.cuda.synchronize()
-        log("sampler warm-up done")
-        t1 = time.perf_counter()
-        x0_hat, _ = smp.sample(net, used[:opt_.sampler_steps])
-        torch.cuda.synchronize()
-        sec = time.perf_counter() - t1
-        log(f"sampler: {sec:.2f}s")
-        sampler = {"steps": min(opt_.sampler_steps, len(used)), "sample_num": args.sample_num, "seconds": round(sec, 3),
-                   "ms_per_step": round(1e3 * sec / min(opt_.sampler_steps, len(used)), 3),
-                   "finite": bool(torch.isfinite(x0_hat).all())}
+        import tempfile
+
+        import numpy as np
+        sampler = {}
+        par = {}
+        pshapes = model.reference_shapes()
+        pparams = parity_params(pshapes)
+        for tag, sdt in (("f32", mdm.F32), ("bf16", mdm.BF16)):
+            if sdt == dt:
+                net = model.with_batch(args.sample_num).eval()
+            else:
+                base = mdm.UNet(cfg, N=args.sample_num, H=32, W=32, dtype=sdt, seed=0, use_graph=not opt_.no_graph)
+                net = base.eval()
+            smp = mdm.Sampler(None, args, sched, [None] * 3)
+            smp.sample(net, used[:3])                            # warm-up / graph capture
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            x0_hat, _ = smp.sample(net, used[:opt_.sampler_steps])
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t1
+            nst = min(opt_.sampler_steps, len(used))
+            log(f"sampler {tag}: {sec:.2f}s")
+            sampler[tag] = {"dtype": tag, "steps": nst, "sample_num": args.sample_num, "seconds": round(sec, 3),
+                            "ms_per_step": round(1e3 * sec / nst, 3), "finite": bool(torch.isfinite(x0_hat).all())}
+            # parity sample: same kernels, non-degenerate weights, the reference's host draws replayed
+            pa = parity_args()
+            pnet = mdm.UNet(cfg, N=PARITY_N, H=32, W=32, dtype=sdt, params=pparams, use_graph=False).eval()
+            psch = mdm.Scheduler(pa, device=dev)
+            psch.update_ddpm_num_steps(1000)
+            pts = psch.get_timesteps_epoch(0, 1)[PARITY_STRIDE - 1::PARITY_STRIDE]
+            _seed_host(PARITY_SEED)
+            px0, _ = mdm.Sampler(None, pa, psch, [None] * 3).sample(pnet, pts)
+            torch.cuda.synchronize()
+            par[tag] = px0.cpu().numpy()
+            del pnet, net
+        fd, parity_file = tempfile.mkstemp(suffix=".npz", prefix="mdm_parity_")
+        os.close(fd)
+        np.savez(parity_file, **par)
 
     cpu = None
     if rank == 0 and world == 1 and not opt_.no_cpu_baseline:
@@ -252,12 +372,30 @@ def main():
         import subprocess
         try:
             env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], env=env,
-                               capture_output=True, text=True, timeout=240)
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
+            if parity_file:
+                cmd += ["--parity-file", parity_file]
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
             sys.stderr.write(r.stderr)
             cpu = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:          # never let the baseline leg take the bench line down
             cpu = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:200]}
+    if parity_file:
+        try:
+            os.unlink(parity_file)
+        except OSError:
+            pass
+    if sampler:
+        # rel-L2 of the GPU sampler's parity sample against the CPU oracle (computed by the cpu_baseline child), per dtype;
+        # the headline entry is the fastest dtype that meets north_star's 1e-3 (fp32 when none does: say so)
+        rels = (cpu or {}).pop("sampler_parity", {}) if isinstance(cpu, dict) else {}
+        for tag in sampler:
+            sampler[tag]["rel_l2_vs_oracle"] = rels.get(tag)
+            sampler[tag]["parity_sample"] = (f"{PARITY_N} images x {1000 // PARITY_STRIDE} reverse steps (every {PARITY_STRIDE}th timestep) of the bench "
+                                             "architecture with non-degenerate random weights, host-replayed draws, vs oracle/sampler_ref.py fp32")
+        ok = [t for t in ("bf16", "f32") if sampler[t]["rel_l2_vs_oracle"] is not None and sampler[t]["rel_l2_vs_oracle"] < 1e-3]
+        head = min(ok, key=lambda t: sampler[t]["seconds"]) if ok else "f32"
+        sampler = {**sampler[head], "meets_1e-3": bool(ok), "by_dtype": sampler}
 
     if rank == 0:
         out = {

@@ -77,11 +77,32 @@ class AdamW:
         return float(self.sqnorm.sqrt())
 
     def state_dict(self):
-        return dict(m=self.m, v=self.v, t=self.t, param_groups=self.param_groups)
+        """`torch.optim.AdamW.state_dict()` layout: per-parameter `step` / `exp_avg` / `exp_avg_sq` in the reference's
+        shapes, indexed in `model.parameters()` order (what accelerate writes to optimizer.bin)."""
+        order = self.model.reference_param_order()
+        m = self.store.state_dict(order=order, src=self.m)
+        v = self.store.state_dict(order=order, src=self.v)
+        state = {i: dict(step=torch.tensor(float(self.t)), exp_avg=m[k], exp_avg_sq=v[k]) for i, k in enumerate(order)} if self.t else {}
+        g = self.param_groups[0]
+        group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     initial_lr=g["initial_lr"], params=list(range(len(order))))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = sd["t"]
-        self.param_groups = sd["param_groups"]
+        order = self.model.reference_param_order()
+        st = sd["state"]
+        if st:
+            assert len(st) == len(order), (len(st), len(order))
+            dev = self.m.device
+            self.m.copy_(self.store.flat_from_reference({k: st[i]["exp_avg"] for i, k in enumerate(order)}).to(dev))
+            self.v.copy_(self.store.flat_from_reference({k: st[i]["exp_avg_sq"] for i, k in enumerate(order)}).to(dev))
+            self.t = int(float(st[0]["step"]))
+        else:
+            self.m.zero_(); self.v.zero_(); self.t = 0
+        g = sd["param_groups"][0]
+        self.param_groups = [dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
+                                  initial_lr=g.get("initial_lr", g["lr"]))]
 
 
 class EMA:
@@ -127,6 +148,20 @@ class EMA:
     def state_dict(self):
         return dict(shadow=self.shadow, optimization_step=self.optimization_step)
 
+    def config(self):
+        """The fields diffusers' EMAModel.save_pretrained adds to the model config (main_train_masked.py:119-127, 200)."""
+        return dict(decay=self.decay, min_decay=self.min_decay, optimization_step=self.optimization_step, update_after_step=0,
+                    use_ema_warmup=self.use_ema_warmup, inv_gamma=self.inv_gamma, power=self.power)
+
+    def load_reference(self, sd, cfg=None):
+        """Shadow parameters from a {reference key: tensor} dict (+ the counters of `config()`)."""
+        self.shadow.copy_(self.pstore.flat_from_reference(sd).to(self.shadow.device))
+        if cfg:
+            self.optimization_step = int(cfg.get("optimization_step", self.optimization_step))
+            for k in ("decay", "min_decay", "use_ema_warmup", "inv_gamma", "power"):
+                if k in cfg:
+                    setattr(self, k, cfg[k])
+
 
 class LambdaLR:
     def __init__(self, optimizer, fn):
@@ -140,6 +175,14 @@ class LambdaLR:
 
     def get_last_lr(self):
         return [self.opt.param_groups[0]["lr"]]
+
+    def state_dict(self):          # torch.optim.lr_scheduler.LambdaLR.state_dict() fields (the lambda itself is not saved)
+        return dict(base_lrs=[self.base], last_epoch=self.k, _step_count=self.k + 1, _last_lr=self.get_last_lr(), lr_lambdas=[None])
+
+    def load_state_dict(self, sd):
+        self.k = int(sd["last_epoch"])
+        self.base = sd["base_lrs"][0]
+        self.opt.param_groups[0]["lr"] = self.base * self.fn(self.k)
 
 
 def get_lr_scheduler(name, optimizer, num_warmup_steps, num_training_steps, num_cycles=0.5):
@@ -186,6 +229,7 @@ class Accelerator:
         self.sync_gradients = True
         self.device = torch.device(device) if device is not None else (
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        self._ckpt = {}
 
     @property
     def is_main_process(self):
@@ -194,6 +238,16 @@ class Accelerator:
     is_local_main_process = is_main_process
 
     def prepare(self, *objs):
+        from .unet import UNet
+        for o in objs:                      # main_train_masked.py:299-307: model, optimizer, dataloader, lr_scheduler
+            if isinstance(o, UNet):
+                self._ckpt["model"] = o
+            elif isinstance(o, AdamW):
+                self._ckpt["optimizer"] = o
+            elif isinstance(o, LambdaLR):
+                self._ckpt["lr_scheduler"] = o
+            elif isinstance(o, EMA):
+                self._ckpt["ema"] = o
         return objs if len(objs) != 1 else objs[0]
 
     def accumulate(self, model):
@@ -214,13 +268,31 @@ class Accelerator:
         if self.is_main_process:
             print(*a, **k)
 
-    def save_state(self, path, model=None, optimizer=None, ema=None):
-        import os
-        os.makedirs(path, exist_ok=True)
-        if self.is_main_process and model is not None:
-            torch.save(model.state_dict(), os.path.join(path, "unet.pt"))
-            if ema is not None:
-                torch.save(model.store.state_dict(src=ema.shadow), os.path.join(path, "unet_ema.pt"))
-            if optimizer is not None:
-                torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()},
-                           os.path.join(path, "optimizer.pt"))
+    def register_for_checkpointing(self, **objs):
+        """model=, optimizer=, ema=, lr_scheduler=, scheduler= : what `save_state(path)` / `load_state(path)` cover.
+        (`prepare()` registers what it recognises; the trainers register the rest.)"""
+        for k, v in objs.items():
+            if v is not None:
+                self._ckpt[k] = v
+
+    def save_state(self, output_dir=None, model=None, optimizer=None, ema=None, **extra):
+        """`accelerator.save_state(path)` (trainer_masked_mean_shift.py:267-268) in the reference's directory
+        layout (mdm/checkpoint.py).  Called with the path alone, like upstream, it saves the registered objects."""
+        from . import checkpoint
+        c = dict(self._ckpt)
+        c.update({k: v for k, v in dict(model=model, optimizer=optimizer, ema=ema).items() if v is not None})
+        if c.get("model") is None:
+            raise RuntimeError("Accelerator.save_state: no model registered (prepare() / register_for_checkpointing())")
+        checkpoint.save_state(output_dir, c["model"], c.get("optimizer"), c.get("ema"), c.get("lr_scheduler"), c.get("scheduler"),
+                              rank=self.process_index, main=self.is_main_process, extra=extra or None)
+        self.wait_for_everyone()
+        return output_dir
+
+    def load_state(self, input_dir=None):
+        """`accelerator.load_state(path)` (main_train_masked.py:268): restores every registered object in place."""
+        from . import checkpoint
+        c = self._ckpt
+        if c.get("model") is None:
+            raise RuntimeError("Accelerator.load_state: no model registered (prepare() / register_for_checkpointing())")
+        return checkpoint.load_state(input_dir, c["model"], c.get("optimizer"), c.get("ema"), c.get("lr_scheduler"), c.get("scheduler"),
+                                     rank=self.process_index)

@@ -25,9 +25,44 @@ HISTORY_NAMES = ["sample_t", "shift", "shifted", "mask", "shifted_result", "samp
                  "degraded_mask", "degraded_mask_next", "degraded_t", "difference", "degraded_next_t"]
 
 
+def shard_bounds(n, rank, world):
+    """[lo, hi) of rank's share when n independent samples are dealt to `world` ranks (the first n % world ranks
+    take one more).  Samples are independent (sampler.py:137-258), so the split needs no collective."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_shards(local, n, group=None):
+    """All-gather of uneven shards along dim 0 -> the full [n, ...] tensor on every rank (the ONE collective of a
+    sharded sampling run, after the loop).  Works on any backend: shards are padded to the largest one."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
+    big = max(sizes)
+    pad = torch.zeros((big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)], 0)
+
+
 class Sampler:
     def __init__(self, dataset, args, Scheduler, dataset_hist):
         self.dataset, self.args, self.Scheduler, self.dataset_hist = dataset, args, Scheduler, dataset_hist
+
+    # ---- multi-GPU: `sample_num` is partitioned over the ranks of the default process group ----------------
+    def _shard(self):
+        """(rank, world) when sharded sampling applies, else (0, 1).  Off with `args.shard_sampling=False`."""
+        import torch.distributed as dist
+        if not getattr(self.args, "shard_sampling", True) or not (dist.is_available() and dist.is_initialized()):
+            return 0, 1
+        return dist.get_rank(), dist.get_world_size()
+
+    def local_sample_num(self):
+        rank, world = self._shard()
+        lo, hi = shard_bounds(self.args.sample_num, rank, world)
+        return hi - lo
 
     def _get_latent_initial(self, model=None):
         """Constant-colour start image per sample, drawn on the host like sampler.py:46-83."""
@@ -59,7 +94,27 @@ class Sampler:
         return mean[:, :, None, None].expand(a.sample_num, a.out_channel, a.data_size, a.data_size)
 
     def sample(self, model, timesteps_used_epoch, interpolation_shift=None):
-        return self._sample_mean_shift_momentum(model, timesteps_used_epoch)
+        """sampler.py:102-106.  With a process group of W ranks every rank runs the loop on its own
+        `local_sample_num()` samples (`model` must be built for that batch; per-rank Philox key, see
+        Scheduler) and the shards are all-gathered once at the end: every rank returns [sample_num, C, H, W]."""
+        rank, world = self._shard()
+        if world == 1:
+            return self._sample_mean_shift_momentum(model, timesteps_used_epoch)
+        import argparse
+        full = self.args
+        n = full.sample_num
+        try:
+            self.args = argparse.Namespace(**vars(full))
+            self.args.sample_num = self.local_sample_num()
+            if self.args.sample_num == 0:
+                raise ValueError(f"sample_num={n} < world size {world}: a rank would sample nothing")
+            x0, hist = self._sample_mean_shift_momentum(model, timesteps_used_epoch)
+        finally:
+            self.args = full
+        def gather_hist(h):             # [T+1, n_local, C, H, W], on the host when args.sample_history is True
+            g = gather_shards(h.to(x0.device).transpose(0, 1).contiguous(), n).transpose(0, 1)
+            return g if h.is_cuda else g.cpu()
+        return gather_shards(x0, n), [gather_hist(h) for h in hist]
 
     # ------------------------------------------------------------------------------
     def _predict(self, model, x_in_nchw, time, fused_nhwc):

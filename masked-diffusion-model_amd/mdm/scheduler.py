@@ -33,9 +33,12 @@ class DeviceRng:
     (recorded like any other launch, so a captured step bumps it on every replay); a host-side counter copied over
     asynchronously would be read late by a GPU that the host runs ahead of."""
 
-    def __init__(self, device, seed=0):
-        self.dev = torch.tensor([int(seed), 0], dtype=torch.int64, device=device) if torch.cuda.is_available() \
-            else torch.tensor([int(seed), 0], dtype=torch.int64)
+    def __init__(self, device, seed=0, rank=0):
+        # key = (seed, rank): data-parallel ranks and sampler shards draw from disjoint streams (the reference seeds
+        # every rank alike, main_train_masked.py:441-445 -- all ranks would draw identical t / masks; SURVEY 8e)
+        key = (int(seed) & 0xFFFFFFFF) | ((int(rank) & 0x7FFFFFFF) << 32)
+        self.dev = torch.tensor([key, 0], dtype=torch.int64, device=device) if torch.cuda.is_available() \
+            else torch.tensor([key, 0], dtype=torch.int64)
 
     def advance(self):
         call("mdm_rng_advance", ptr(self.dev), stream())
@@ -74,7 +77,11 @@ class Scheduler:
             self.device = torch.device("cpu")
         self.rng_mode = getattr(args, "rng_mode", "replay")
         self.reference_quirks = getattr(args, "reference_quirks", True)
-        self.dev_rng = DeviceRng(self.device, getattr(args, "seed", 0))
+        rank = getattr(args, "rng_rank", None)
+        if rank is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.dev_rng = DeviceRng(self.device, getattr(args, "seed", 0), rank)
 
     # ---- schedule tables (host, once per run) -------------------------------------
     def update_ddpm_num_steps(self, max_time=None):
@@ -104,8 +111,15 @@ class Scheduler:
             raise ValueError("Invalid mask ratio scheduler")
         self.updated_ddpm_num_steps = len(self.ratio_list)
         self.reverse_ratio = torch.flip(self.ratio_list, dims=(0,))
-        self.ratio_dev = self.ratio_list.to(self.device)
-        self.pixels_dev = torch.as_tensor(np.asarray(self.black_area_pixels)).to(self.device)
+        # the device tables keep their addresses across calls (captured graphs hold raw pointers to them)
+        def put(name, host):
+            old = getattr(self, name, None)
+            if old is not None and old.shape == host.shape and old.dtype == host.dtype:
+                old.copy_(host)
+            else:
+                setattr(self, name, host.to(self.device))
+        put("ratio_dev", self.ratio_list)
+        put("pixels_dev", torch.as_tensor(np.asarray(self.black_area_pixels)))
         return self.updated_ddpm_num_steps
 
     def get_black_area_num_pixels_all(self):

@@ -36,6 +36,10 @@ class Trainer:
         ema = ema_model if getattr(args, "use_ema", False) else None
         self.step = TrainStep(model, self.Scheduler, args, optimizer, ema, mean_shift=self.mean_shift, comm=comm)
         self.loss_names = ["train_loss"]
+        # what `accelerator.save_state(path)` / `load_state(path)` cover (main_train_masked.py:195-225 hooks)
+        reg = getattr(accelerator, "register_for_checkpointing", None)
+        if reg is not None:
+            reg(model=model, optimizer=optimizer, ema=ema, lr_scheduler=lr_scheduler, scheduler=self.Scheduler)
 
     # ------------------------------------------------------------------------------------------
     def _batch_images(self, input):
@@ -87,14 +91,16 @@ class Trainer:
             loss = self._epoch_losses(self._run_epoch(epoch, epoch_length, resume_step, dirs, visualizer))
             if self.accelerator.is_main_process:
                 loss_mean_epoch.append(statistics.mean(loss))
-                last = epoch == (epoch_start + epoch_length - 1)
-                if (epoch > 0 and (epoch + 1) % a.save_images_epochs == 0) or last or \
-                        (epoch + 1) % (epoch_length / a.scheduler_num_scale_timesteps) == 0:      # ms:252
-                    if getattr(a, "use_ema", False) and getattr(a, "sampling", "momentum") == "momentum":
-                        self._save_ema_momentum_sample(dirs, epoch)
-                    save_path = os.path.join(dirs.list_dir["checkpoint"], f"checkpoint-epoch-{epoch}")
-                    self.accelerator.save_state(save_path, self.model, self.optimizer,
-                                                self.ema_model if getattr(a, "use_ema", False) else None)
+            last = epoch == (epoch_start + epoch_length - 1)
+            if (epoch > 0 and (epoch + 1) % a.save_images_epochs == 0) or last or \
+                    (epoch + 1) % (epoch_length / a.scheduler_num_scale_timesteps) == 0:      # ms:252
+                # Upstream does this block on the main process only (ms:244).  Here EVERY rank enters it: the
+                # reverse sampler shards `sample_num` over the ranks and save_state ends in a barrier;
+                # files are still written by the main process alone.
+                if getattr(a, "use_ema", False) and getattr(a, "sampling", "momentum") == "momentum":
+                    self._save_ema_momentum_sample(dirs, epoch)
+                save_path = os.path.join(dirs.list_dir["checkpoint"], f"checkpoint-epoch-{epoch}")
+                self.accelerator.save_state(save_path)                                           # ms:267-268
         self.loss_mean_epoch = loss_mean_epoch
 
     def _save_ema_momentum_sample(self, dirs, epoch):
@@ -102,12 +108,14 @@ class Trainer:
         a = self.args
         self.ema_model.store(None)
         self.ema_model.copy_to(None)
-        net = self.model.with_batch(a.sample_num).eval()
-        sample_0, _hist = self.Sampler.sample(net, self.timesteps_used_epoch)
+        net = self.model.with_batch(self.Sampler.local_sample_num()).eval()      # this rank's share of sample_num
+        sample_0, _hist = self.Sampler.sample(net, self.timesteps_used_epoch)    # gathered: [sample_num, C, H, W] on every rank
         self.ema_model.restore(None)
         self.model.train()
         self.ema_sample = sample_0
-        torch.save(sample_0.cpu(), os.path.join(dirs.list_dir["ema_sample_img"], f"ema_sample_{epoch:05d}.pt"))
+        self.ema_sample_mean = sample_0.mean()                                   # ms:421
+        if self.accelerator.is_main_process:
+            torch.save(sample_0.cpu(), os.path.join(dirs.list_dir["ema_sample_img"], f"ema_sample_{epoch:05d}.pt"))
         return sample_0
 
 

@@ -170,6 +170,14 @@ class ParamStore:
     def grad_dict(self):
         return self.state_dict(src=self.G)
 
+    def flat_from_reference(self, sd, fill=0.0):
+        """Host flat fp32 buffer (this store's layout) from a {reference key: tensor in reference shape} dict
+        (optimizer moments of a checkpoint: same keys and shapes as the weights)."""
+        host = torch.full((self.size,), float(fill), dtype=torch.float32)
+        for k, e in self.entries.items():
+            host[e.off:e.off + e.n] = self.to_internal(k, sd[k]).reshape(-1)
+        return host
+
 
 # --------------------------------------------------------------------------- #
 class _Conv:
@@ -442,7 +450,10 @@ class UNet:
         """A second launch plan over the SAME weights for another batch size (e.g. sample_num)."""
         if N == self.N:
             return self
-        return UNet(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph)
+        plans = self.__dict__.setdefault("_batch_plans", {})
+        if N not in plans:
+            plans[N] = UNet(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph)
+        return plans[N]
 
     # ---- construction ---------------------------------------------------------
     def _act(self, name, H, W, C, needs_grad=True):
@@ -558,6 +569,31 @@ class UNet:
 
     def reference_shapes(self):
         return OrderedDict((k, e.rshape) for k, e in self.store.entries.items())
+
+    def reference_param_order(self):
+        """The 304 keys in the order `model.parameters()` yields them upstream = module registration order
+        (unet6.py:395-415: embed, in_conv, downsamples.level_0.., middle, upsamples.level_0.., out_conv; inside a
+        ResidualBlock norm1, conv1, fc, norm2, conv2, skip (:349-354); AttentionBlock norm, project_in, project_out
+        (:307-310)).  torch.optim state dicts index parameters by this order."""
+        top = {"embed": 0, "in_conv": 1, "downsamples": 2, "middle": 3, "upsamples": 4, "out_conv": 5}
+        member = {"norm1": 0, "conv1": 1, "fc": 2, "norm2": 3, "conv2": 4, "skip": 5, "norm": 0, "project_in": 1, "project_out": 2}
+
+        def rank(key):
+            parts = key.split(".")
+            r = [top[parts[0]]]
+            for q in parts[1:]:
+                if q.startswith("level_"):
+                    r.append(int(q[6:]))
+                elif q.isdigit():
+                    r.append(int(q))
+                elif q in member:
+                    r.append(member[q])
+                elif q in ("weight", "bias"):
+                    r.append(0 if q == "weight" else 1)
+                else:
+                    raise KeyError(key)
+            return r
+        return sorted(self.store.entries, key=rank)
 
     def alloc(self, shape, dtype):
         t = torch.zeros(tuple(shape), device=self.device, dtype=dtype)

@@ -77,3 +77,21 @@ def test_two_ranks_one_gpu_gloo(tmp_path, mode):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert "DPGPU_OK" in outs[0]
+
+
+def test_bench_gpus_2_prints_a_two_rank_line():
+    """`python bench.py --gpus 2` (no torchrun environment) starts two ranks itself and reports n_gpus = 2.
+    One card here: both ranks on cuda:0 over gloo (MDM_FORCE_DEVICE / MDM_DIST_BACKEND); the driver's runs use one
+    rank per GPU over RCCL."""
+    import json
+    env = dict(os.environ, MDM_FORCE_DEVICE="0", MDM_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8",
+                        "--no-cpu-baseline", "--no-sampler"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak"

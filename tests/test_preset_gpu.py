@@ -1,0 +1,99 @@
+"""GPU parity AT THE BENCHMARKED CONFIGURATION: the 35.75 M-parameter `Model('unet6',3,32,32,3)` preset
+(reference models_Unet.py:132-171, unet6.py:365-506) at N=4 and N=32 (bench.py's batch), fp32 and bf16:
+forward and ALL 304 parameter gradients against the CPU oracle's autograd -- launched eagerly and
+through one captured hipGraph (the way bench.py runs it)."""
+import functools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).float().cpu()
+    b = torch.as_tensor(b).float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@functools.lru_cache(maxsize=None)
+def _case(n):
+    """(params, x, t, gy, oracle y, oracle grads) for batch n -- computed once per session."""
+    from mdm.unet import unet6_config
+    from oracle.unet_ref import UNetRef, random_params
+    cfg = unet6_config(32)
+    p = random_params(cfg, 77)
+    g = torch.Generator().manual_seed(1000 + n)
+    x = torch.rand(n, 3, 32, 32, generator=g) * 2 - 1
+    t = torch.randint(1, 1001, (n,), generator=g).float()
+    gy = torch.randn(n, 3, 32, 32, generator=g) / n
+    m = UNetRef(cfg, p)
+    yo = m(x, t).sample
+    (yo * gy).sum().backward()
+    want = {k: q.grad.detach().clone() for k, q in zip(m.keys, m.plist)}
+    return cfg, p, x, t, gy, yo.detach(), want
+
+
+def _check_grads(grads, want, tol_g, tag):
+    assert set(grads) == set(want) and len(want) == 304
+    a = torch.cat([grads[k].reshape(-1) for k in want])
+    b = torch.cat([want[k].reshape(-1) for k in want])
+    assert bool(torch.isfinite(a).all()), tag
+    assert _rel(a, b) < tol_g, (tag, _rel(a, b))
+    # every tensor whose oracle gradient is not negligible next to its peers, one by one (a wrong kernel
+    # variant on ONE layer hides in the global norm)
+    med = sorted(float(w.norm()) for w in want.values())[len(want) // 2]
+    keys = [k for k in want if float(want[k].norm()) > 1e-2 * med]
+    assert len(keys) > 0.9 * len(want), len(keys)
+    worst = max((_rel(grads[k], want[k]), k) for k in keys)
+    assert worst[0] < 2 * tol_g, (tag, worst)
+
+
+@pytest.mark.parametrize("n", [4, 32])
+@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
+def test_preset_forward_and_all_gradients_eager_and_graph(n, dt, tol_y, tol_g):
+    from mdm import _lib, ops
+    from mdm import unet as U
+    cfg, p, x, t, gy, yo, want = _case(n)
+    net = U.UNet(cfg, N=n, H=32, W=32, dtype=dt, params=p, use_graph=False)
+    assert net.num_parameters() == 35746307
+    dev = net.device
+
+    def load_inputs():
+        net.x_nchw.copy_(x)
+        net.t_in.copy_(t)
+        ops.nchw_to_nhwc(dt, net.x_nchw, net.x_in.data, n, 3, 32, 32, net.cin_p)
+        ops.nchw_to_nhwc(dt, gy.to(dev), net.y_out.grad, n, 3, 32, 32, net.cout_p)
+
+    def read_y():
+        ops.nhwc_to_nchw(dt, net.y_out.data, net.y_nchw, n, 3, 32, 32, net.cout_p)
+        return net.y_nchw.cpu()
+
+    # ---- eager launch list
+    load_inputs()
+    net.zero_grad()
+    net.forward_plan.run()
+    net.backward_plan.run()
+    torch.cuda.synchronize()
+    y_e, g_e = read_y(), net.store.grad_dict()
+    assert _rel(y_e, yo) < tol_y, _rel(y_e, yo)
+    _check_grads(g_e, want, tol_g, f"eager n={n} dt={dt}")
+
+    # ---- the same two plans as ONE captured hipGraph, replayed twice (second replay = what bench.py times)
+    whole = _lib.Recording()
+    whole.extend(net.forward_plan)
+    whole.extend(net.backward_plan)
+    gexec = _lib.GraphExec(whole)
+    for _ in range(2):
+        net.y_out.data.zero_()
+        net.zero_grad()
+        load_inputs()
+        gexec.launch()
+    torch.cuda.synchronize()
+    y_g, g_g = read_y(), net.store.grad_dict()
+    assert _rel(y_g, yo) < tol_y, _rel(y_g, yo)
+    _check_grads(g_g, want, tol_g, f"graph n={n} dt={dt}")
+    # graph == eager up to the reordering noise of the float atomics (dgamma / dbeta / bias sums)
+    a = torch.cat([g_g[k].reshape(-1) for k in want])
+    b = torch.cat([g_e[k].reshape(-1) for k in want])
+    assert _rel(a, b) < (1e-5 if dt == 0 else 5e-3), _rel(a, b)
