@@ -712,7 +712,8 @@ class UNet:
         self.store.load_state_dict(sd)
 
     def state_dict(self):
-        return self.store.state_dict()
+        """Reference key grammar, reference shapes, `model.parameters()` order."""
+        return self.store.state_dict(order=self.reference_param_order())
 
     def parameters(self):
         return [self.store.P]
