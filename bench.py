@@ -269,9 +269,9 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         with _lib.Recording() as front:
             step._emit_device_front()
-        # the family = every bf16 mdm_gemm call plus the batched split-K sum that finishes the weight gradients
+        # the family = every bf16 mdm_gemm call plus the grouped weight-gradient launches (incl. their split-K sums)
         pick = lambda rec: (lambda i, name: (name == "mdm_gemm" and rec.flops.get(i, (0, -1))[1] == dt) or
-                            name == "mdm_splitk_reduce_pending")
+                            name == "mdm_wgrad_group_launch")
         tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
         reps = 3
         # an event pair is not free: measured on the forward contractions as 2 T(one launch) - T(two launches)

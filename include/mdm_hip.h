@@ -95,25 +95,17 @@ typedef struct mdm_gemm_desc {
      * sum of dY, which the weight-gradient kernel already holds as MFMA fragments: one extra MFMA against
      * a ones-fragment per k-step in the tap-0 / first-column workgroups, fp32 atomics at the end). */
     float* dbias;
-    /* split-K through ws: 1 = do NOT launch the summing kernel; the (ws, splits, D0) triple is queued in the
-     * library and summed by the next mdm_splitk_reduce_pending() -- ONE launch for every queued contraction
-     * (the weight gradients of a whole backward chunk) instead of one ~5 us launch each.  ws must stay
-     * untouched until then (give every deferred call its own slice). */
-    int32_t defer_reduce;
-    /* weight gradients on the linear-gather kernel only, with defer_reduce: 1 = queue this contraction instead of
-     * launching it; it shares ONE launch with the next such contraction (the conv2 / conv1 pair of a residual
-     * block), or is launched by mdm_gemm_flush() / mdm_splitk_reduce_pending().  Its operands must stay
-     * untouched until then. */
-    int32_t defer_launch;
     /* Fused GroupNorm backward (unet6.py:291-293 backward) in the epilogue of the DATA GRADIENT of the conv that
      * consumes the normalised tensor, on the whole-image tiles of the 4x4 / 8x8 maps (mdm_gemm_can_fuse_gn_bwd says
      * whether this descriptor qualifies): the contraction result is d(z), z = silu?(GroupNorm(x)); instead of storing
      * it, the epilogue reads x, stats (mean, rstd per image and group), gamma, beta and writes dx into D0 (acc0 honoured),
      * adds dgamma / dbeta, and optionally the column sums of dx (gnb_sum_img[n * gnb_sum_ld + c] = sum_p dx,
-     * gnb_sum_all[c] += sum_{n,p} dx) like mdm_groupnorm_bwd_sums.  NULL gnb_x = plain epilogue. */
+     * gnb_sum_all[c] += sum_{n,p} dx) like mdm_groupnorm_bwd_sums.  gnb_add (with acc0 == 0): a tensor laid out like D0
+     * whose values are added to dx (the gradient arriving over the residual branch, unet6.py:362).  NULL gnb_x = plain epilogue. */
     const void* gnb_x; const float* gnb_stats; const float* gnb_gamma; const float* gnb_beta;
     float* gnb_dgamma; float* gnb_dbeta; float* gnb_sum_img; float* gnb_sum_all;
     int32_t gnb_G, gnb_silu, gnb_sum_ld, _p3;
+    const void* gnb_add;
     /* Fused GroupNorm FORWARD in the epilogue of the conv that PRODUCES the tensor, same tiles (mdm_gemm_can_fuse_gn_fwd):
      * after the usual epilogue has stored y (bf16), the workgroup normalises the values it just rounded:
      * gnf_out = silu?(GroupNorm_G(y) * gamma + beta) (bf16, same shape as y), gnf_stats[n][g] = (mean, rstd).
@@ -123,14 +115,6 @@ typedef struct mdm_gemm_desc {
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
-/* Sums every queued split-K partial (see defer_reduce) into its destination and empties the queue.
- * The queue is per host thread; queue and launch must be recorded/captured in the same order they are replayed. */
-int mdm_splitk_reduce_pending(void* stream);
-/* Launches every queued (defer_launch) contraction. */
-int mdm_gemm_flush(void* stream);
-/* Forgets every queued launch and reduction of this host thread WITHOUT running them (error recovery: a launch
- * sequence that was abandoned half-way must not leave pointers behind for the next mdm_splitk_reduce_pending). */
-int mdm_gemm_discard_pending(void);
 /* What mdm_gemm would choose for this descriptor given unlimited workspace: the split count and the
  * workspace bytes it needs (0 when it would not use partial slabs).  No launch. */
 int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out);
@@ -139,6 +123,31 @@ int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_b
 int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G);
 /* the same question for the gnf_* epilogue of a bf16 3x3 forward convolution */
 int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G);
+
+/* ------------------------------------------------------------------------- *
+ * A GROUP of weight gradients in ONE launch (autograd's conv2d weight gradient, unet6.py:232-235).
+ * The weight gradient of a convolution only READS dY and the layer input; both stay in memory until the end of
+ * the backward pass, so the host may collect the (layout 2, conv) descriptors of a whole stretch of the backward
+ * and run them together: every contraction is cut into work items (output tile x filter tap x k-range), the items of
+ * all layers are sorted longest first and launched as one flat grid, followed by ONE launch that sums the split-K
+ * partial slabs of the layers that were split.  The group fills the chip, so a layer needs only the k-splits that
+ * balance asks for (descriptor.splitk > 0 is honoured, 0 = the per-layer rule of mdm_gemm).
+ *   mdm_wgrad_group_accepts   1 if the descriptor can be a member (bf16, layout 2, conv, dense fp32 [tap][M][N] output,
+ *                             geometry of the linear-gather kernel), else 0 (run it through mdm_gemm instead).
+ *   mdm_wgrad_group_create    resolves the n HOST descriptors (operands must already be the final device pointers;
+ *                             a descriptor with splitk > 1 needs its own ws slice), builds the item table and copies
+ *                             both into dev_buf (device memory owned by the caller, kept alive as long as the handle).
+ *                             *need_bytes_out = bytes dev_buf must hold; with dev_buf == NULL or too small nothing is
+ *                             built (*handle_out = NULL, return 0): call once to size, once to build.  Synchronous
+ *                             (hipMemcpy): call it outside stream capture.
+ *   mdm_wgrad_group_launch    the two launches, stream-ordered and capturable.  D0 = (acc0 ? D0 : 0) + dW.
+ *   mdm_wgrad_group_destroy   frees the host-side handle (not dev_buf).
+ * ------------------------------------------------------------------------- */
+int mdm_wgrad_group_accepts(const mdm_gemm_desc* desc_host);
+int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, void* dev_buf, int64_t dev_bytes,
+                           int64_t* need_bytes_out, void** handle_out);
+int mdm_wgrad_group_launch(void* handle, void* stream);
+int mdm_wgrad_group_destroy(void* handle);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)
@@ -166,6 +175,14 @@ int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1
                            const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
                            float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, float* ws,
                            void* stream);
+/* The general form: dst = add + dx, where add0 / add1 (NULL = none) are tensors laid out like dst0 / dst1 -- dst itself
+ * gives the accumulating form above; another tensor adds the gradient that arrives over a residual branch
+ * (x + block(x), unet6.py:333, 362) WITHOUT modifying that tensor, which a later (grouped) weight gradient still reads. */
+int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1, int C1,
+                          int N, int P, int G, const float* gamma, const float* beta, int silu,
+                          const void* dy, const float* stats, void* dst0, const void* add0, void* dst1, const void* add1,
+                          float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, float* ws,
+                          void* stream);
 
 /* row softmax of S[rows][L] in place (unet6.py:320-322), and its backward
  * dS = P * (dP - sum_j dP*P) written over dP. */
@@ -189,6 +206,8 @@ int mdm_sumpool2(int dtype, const void* g, void* dst, int acc, int N, int H, int
 
 /* dst += src over n elements of `dtype` (n % 8 == 0): joins two gradient contributions of one activation */
 int mdm_add(int dtype, void* dst, const void* src, int64_t n, void* stream);
+/* dst = x + y (y == NULL: dst = x) */
+int mdm_add3(int dtype, void* dst, const void* x, const void* y, int64_t n, void* stream);
 
 /* layout converters: NCHW fp32 <-> NHWC dtype with the channel count padded to Cp (pad = 0) */
 int mdm_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int Cp, void* stream);

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <algorithm>
 #include <vector>
 
 namespace mdm {
@@ -972,152 +973,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 }
 
 // ----------------------------------------------------------------------------
-// Specialised ring kernel for the bulk of the convolutions: layout 0 (both operands k-contiguous),
-// stride 1, no folded upsample -- every 3x3 / 1x1 forward and (through the transposed weight
-// shadow) every such data gradient.  There the source pixel is LINEAR in the filter tap:
-//     spix(tap) = base0 + sgn * (ty * IW + tx)
-// so each lane keeps one row pointer per source and a 9-bit validity mask per row, and the slab
-// loop carries almost no address arithmetic: per LDS-DMA piece one 64-bit add of a wave-uniform
-// offset and one select against the zero page.  The loop is unrolled over the ring so stage
-// addresses are immediates.  (PMC on the general kernel: ~100 SALU + ~85 VALU per slab per wave
-// for 16 MFMAs -- instruction issue, not memory, was the limiter.)
-// ----------------------------------------------------------------------------
-template <int BM, int BN, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW) void conv_lin_kernel(mdm_gemm_desc d) {
-    constexpr int BK = 64;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;
-    constexpr int WROWS = NW / 2;
-    constexpr int WM = BM / WROWS, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-    extern __shared__ __attribute__((aligned(1024))) char ring[];
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int tiles_n = (d.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page);
-    const int sk = d.splitk < 1 ? 1 : d.splitk;
-    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.nouter = 1; z.ks = blockIdx.z;
-
-    const int r_sub = lane >> 3, r_lch = (lane & 7) ^ r_sub;
-    const int sgn = d.transposed ? -1 : 1;
-    const int ntaps = d.KH * d.KW;
-
-    // ---- per-row state: pointer to tap (0,0) in each source (may point outside; only used when valid) + validity bits
-    const char* a_row0[GA];
-    const char* a_row1[GA];
-    unsigned a_vmask[GA];
-#pragma unroll
-    for (int j = 0; j < GA; ++j) {
-        const int gm = m0 + 8 * (wave * GA + j) + r_sub;
-        RowPix rp = decode_row(d, gm < d.M ? gm : 0);
-        const int by = d.transposed ? rp.oy + d.pad_t : rp.oy - d.pad_t;
-        const int bx = d.transposed ? rp.ox + d.pad_l : rp.ox - d.pad_l;
-        unsigned vm = 0;
-        for (int ty = 0; ty < d.KH; ++ty)
-            for (int tx = 0; tx < d.KW; ++tx) {
-                int iy = by + sgn * ty, ix = bx + sgn * tx;
-                bool ok = gm < d.M && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
-                vm |= (ok ? 1u : 0u) << (ty * d.KW + tx);
-            }
-        a_vmask[j] = vm;
-        const int64_t base0 = ((int64_t)rp.img * d.IH + by) * d.IW + bx;
-        a_row0[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src0) + base0 * d.ld0 + 8 * r_lch);
-        a_row1[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src1) + base0 * d.ld1 + 8 * r_lch);
-    }
-    const char* b_row[GB];
-    bool b_ok[GB];
-#pragma unroll
-    for (int j = 0; j < GB; ++j) {
-        const int gn = n0 + 8 * (wave * GB + j) + r_sub;
-        b_ok[j] = gn < d.N;
-        b_row[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(b_ok[j] ? gn : 0) * d.ldb + 8 * r_lch);
-    }
-
-    // ---- wave-uniform slab cursor of the ISSUE side: (tap, source, channel)
-    const int tps = ntaps / sk;
-    const int tap_beg = z.ks * tps;
-    int i_tap = tap_beg, i_ty = tap_beg / d.KW, i_tx = tap_beg - (tap_beg / d.KW) * d.KW, i_src = 0, i_c = 0;
-    const int nk = tps * (d.Ck / BK);
-    int issued = 0;
-
-    auto issue = [&](char* stage) {
-        const bool live = issued < nk;                                   // over-issued tail slabs re-read slab (0,0,0): harmless
-        const int tap = live ? i_tap : tap_beg, src = live ? i_src : 0, c = live ? i_c : 0;
-        const int ty = live ? i_ty : tap_beg / d.KW, tx = live ? i_tx : tap_beg - (tap_beg / d.KW) * d.KW;
-        const int ld = src ? d.ld1 : d.ld0;
-        const int64_t aoff = ((int64_t)(sgn * (ty * d.IW + tx)) * ld + c) * 2;            // bytes, wave-uniform
-        const int64_t boff = ((int64_t)tap * d.wtap + c + (src ? d.C0 : 0)) * 2;
-#pragma unroll
-        for (int j = 0; j < GA; ++j) {
-            const char* p = (src ? a_row1[j] : a_row0[j]) + aoff;
-            lds_dma16((((a_vmask[j] >> tap) & 1u) && !(d._p0 & 1)) ? p : zero, stage + (wave * GA + j) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < GB; ++j)
-            lds_dma16((b_ok[j] && !(d._p0 & 2)) ? b_row[j] + boff : zero, stage + A_BYTES + (wave * GB + j) * 1024);
-        ++issued;
-        i_c += BK;
-        if (i_c >= (i_src ? d.C1 : d.C0)) {
-            i_c = 0;
-            if (++i_src == (d.C1 > 0 ? 2 : 1)) {
-                i_src = 0; ++i_tap;
-                if (++i_tx == d.KW) { i_tx = 0; ++i_ty; }
-            }
-        }
-    };
-
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int s2 = 0; s2 < NSTAGE - 1; ++s2) issue(ring + s2 * STAGE_BYTES);
-
-    for (int it0 = 0; it0 < nk; it0 += NSTAGE) {
-#pragma unroll
-        for (int s2 = 0; s2 < NSTAGE; ++s2) {             // stage index == s2: LDS addresses are immediates
-            if (it0 + s2 < nk) {
-                wait_vmcnt<(NSTAGE - 2) * G>();
-                __builtin_amdgcn_s_barrier();
-                issue(ring + ((s2 + NSTAGE - 1) % NSTAGE) * STAGE_BYTES);
-                const char* As = ring + s2 * STAGE_BYTES;
-                const char* Bs = As + A_BYTES;
-#pragma unroll
-                for (int ks = 0; ks < BK / 32; ++ks) {
-                    bf16x8 af[MI], bfr[NI];
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) af[i] = ring_frag_rows(As, wr * WM + i * 16, ks, lane);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) bfr[j] = ring_frag_rows(Bs, wc * WN + j * 16, ks, lane);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-    }
-    wait_vmcnt<0>();
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        int m = m0 + wr * WM + i * 16 + (lane & 15);
-        if (m >= d.M) continue;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
-            if (n < d.N) epilogue4<bf16_t>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
-        }
-    }
-}
-
-
-// ----------------------------------------------------------------------------
-// conv_lin2: the same contraction as conv_lin_kernel with the ISSUE side reduced to its minimum.
-// The ISA of conv_lin_kernel spends ~120 scalar + ~70 vector instructions per k-slab per wave around
+// conv_lin2: ring kernel for the bulk of the convolutions -- layout 0 (both operands k-contiguous), stride 1 (or the
+// stride-2 forward), no folded upsample: every 3x3 / 1x1 forward and (through the transposed weight shadow) every such
+// data gradient.  There the source pixel is LINEAR in the filter tap, spix(tap) = base0 + sgn * (ty * IW + tx), so a lane
+// keeps one row pointer per source and a 9-bit validity mask per row.  The ISSUE side is reduced to its minimum:
+// the first version of this kernel spent ~120 scalar + ~70 vector instructions per k-slab per wave around
 // 16 MFMAs (tap decode, selects against the zero page, M0 through readfirstlane); with both waves of a
 // SIMD in lockstep behind the slab barrier that instruction stream, not MFMA/LDS/L2, sets the slab time.
 // Here every LDS-DMA piece owns ONE 64-bit pointer that is re-aimed only when the (tap, source) segment
@@ -1186,7 +1046,7 @@ __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds,
 // fp32 partial tile of a split-K contraction -> its slab, through LDS: 16-byte stores, 512 B contiguous per 32 lanes
 // (the MFMA layout stores 64-B pieces over 16 rows per instruction)
 template <int BM, int BN, int NW, int MI, int NI>
-__device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, const ZInfo& z, char* lds, int m0, int n0,
+__device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, float* slab, char* lds, int m0, int n0,
                                                    int row_w, int col_w, int lane, int t, f32x4 (&acc)[MI][NI]) {
     constexpr int PITCH = BN * 4;
 #pragma unroll
@@ -1200,7 +1060,6 @@ __device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, const
         }
     }
     __syncthreads();
-    float* slab = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * z.nouter + z.outer) * ((int64_t)d.M * d.N);
     constexpr int CPR = BN / 4;
 #pragma unroll 4
     for (int idx = t; idx < BM * CPR; idx += 64 * NW) {
@@ -1311,8 +1170,8 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     {
         bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
         float8 v = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-        if (d.acc0) {
-            const float8 old = load8(p);
+        if (d.acc0 || d.gnb_add) {         // accumulate in place, or add a tensor laid out like D0 (the residual branch's gradient)
+            const float8 old = load8(d.acc0 ? p : reinterpret_cast<const bf16_t*>(d.gnb_add) + (int64_t)m * d.ldd0 + n);
             v.lo.x += old.lo.x; v.lo.y += old.lo.y; v.lo.z += old.lo.z; v.lo.w += old.lo.w;
             v.hi.x += old.hi.x; v.hi.y += old.hi.y; v.hi.z += old.hi.z; v.hi.w += old.hi.w;
         }
@@ -1476,7 +1335,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tile_i = (d._p0 & 8) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // opt-in: measured no gain at cfg2
+    const int tile_i = (int)blockIdx.x;         // (an XCD-aware remap of the tile index was measured: no gain at cfg2)
     const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int sk = d.splitk < 1 ? 1 : d.splitk;
@@ -1502,7 +1361,6 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
                 bool ok = gm < d.M && (unsigned)iy < (unsigned)d.IH && (unsigned)ix < (unsigned)d.IW;
                 vm |= (ok ? 1u : 0u) << (ty * d.KW + tx);
             }
-        if (d._p0 & 1) vm = 0;
         a_vmask[j] = vm;
         const int64_t base0 = ((int64_t)rp.img * d.IH + by) * d.IW + bx;
         a_row0[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.src0) + base0 * d.ld0 + 8 * r_lch);
@@ -1513,7 +1371,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
         const int gn = n0 + 8 * (wave * GB + j) + r_sub;
-        b_ok[j] = gn < d.N && !(d._p0 & 2);
+        b_ok[j] = gn < d.N;
         b_row[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(gn < d.N ? gn : 0) * d.ldb + 8 * r_lch);
     }
 
@@ -1723,7 +1581,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
                 acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
             }
     }
-    const bool tile_epi = WK == 1 && !(d.splitk > 1 && d.ws) && !d.out_f32 && (d.N & 7) == 0 && (d.N0 & 7) == 0 && !(d._p0 & 4);
+    const bool tile_epi = WK == 1 && !(d.splitk > 1 && d.ws) && !d.out_f32 && (d.N & 7) == 0 && (d.N0 & 7) == 0;
     if (tile_epi) {
         __syncthreads();                // every wave is done with the ring (tail DMA landed: vmcnt(0) above)
         epilogue_tile<BM, BN, NW, MI, NI>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
@@ -1779,7 +1637,6 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
     const int tiles_n = (d.N + BN - 1) / BN;
     // work item order: k-range major, then filter tap, then output tile -- a contiguous run per XCD (xcd_remap)
     const int sk = d.splitk < 1 ? 1 : d.splitk, ntap = d.KH * d.KW, per_k = ntap * tiles_x;
-    if (d._p0 & 8) item = xcd_remap(item, per_k * sk);        // measured: no gain at cfg2 (L2 hit rate is not the limiter)
     const int ks_i = item / per_k, rem_i = item - ks_i * per_k, tap_i = rem_i / tiles_x, tile_i = rem_i - tap_i * tiles_x;
     const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
     ZInfo z; z.batch = 0; z.tap = tap_i; z.outer = tap_i; z.nouter = ntap; z.ks = ks_i; z.kbeg = 0; z.kend = d.K;
@@ -1822,7 +1679,7 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
         // (stride 2: unet6.py:257-272; folded nearest x2 upsample: unet6.py:472).  A slab is rows_per_slab whole output
         // rows, so the physical row advances by (rows_per_slab * s) >> ups per slab -- also across image boundaries.
         const int vx = x * d.stride + dxx, vy = y * d.stride + dyy;
-        b_xok[j] = gn < d.N && (unsigned)vx < (unsigned)d.IW && !(d._p0 & 2);
+        b_xok[j] = gn < d.N && (unsigned)vx < (unsigned)d.IW;
         const bool s1 = gn >= d.C0;
         const int ld = s1 ? d.ld1 : d.ld0;
         const bf16_t* S = reinterpret_cast<const bf16_t*>(s1 ? d.src1 : d.src0);
@@ -1910,9 +1767,15 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
             if (m < d.M) atomicAdd(&d.dbias[m], accb[i][0]);
         }
     }
-    if (d.splitk > 1 && d.ws && (d.N & 3) == 0 && !(d._p0 & 4)) {          // uniform: partial slab, wide stores through LDS
+    if (d.splitk > 1 && d.ws && (d.N & 3) == 0) {          // uniform: partial slab, wide stores through LDS
         __syncthreads();                // every wave is done with the ring (tail DMA landed: vmcnt(0) above)
-        epilogue_tile_slab<BM, BN, NW, MI, NI>(d, z, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        float* slab = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * z.nouter + z.outer) * ((int64_t)d.M * d.N);
+        epilogue_tile_slab<BM, BN, NW, MI, NI>(d, slab, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+    } else if (d.splitk <= 1 && d.out_f32 && !d.acc0 && d.ldd0 == d.N && d.N0 == d.N && (d.N & 3) == 0 && d.alpha == 1.0f) {
+        // unsplit, overwriting, dense fp32 destination (the weight gradient of a small map): the gradient IS the slab
+        __syncthreads();
+        float* slab = reinterpret_cast<float*>(d.D0) + z.tap * d.dtap;
+        epilogue_tile_slab<BM, BN, NW, MI, NI>(d, slab, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -1939,17 +1802,24 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
 }
 
 
-// One launch = one or two weight gradients (flat 1-D grid of work items).  Two: the conv2 / conv1 pair of a
-// residual block -- independent leaves of the backward, the same kernel, so the pair shares one launch gap
-// and the tail of the first overlaps the head of the second (mdm_gemm: defer_launch).
 template <int BM, int BN, int NSTAGE, int NW>
 __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d, int tiles_x) {
     wgrad_lin_body<BM, BN, NSTAGE, NW>(d, (int)blockIdx.x, tiles_x);
 }
-template <int BM, int BN, int NSTAGE, int NW>
-__global__ __launch_bounds__(64 * NW) void wgrad_lin_pair_kernel(mdm_gemm_desc d0, int tiles_x0, int items0, mdm_gemm_desc d1, int tiles_x1) {
-    if ((int)blockIdx.x < items0) wgrad_lin_body<BM, BN, NSTAGE, NW>(d0, (int)blockIdx.x, tiles_x0);
-    else wgrad_lin_body<BM, BN, NSTAGE, NW>(d1, (int)blockIdx.x - items0, tiles_x1);
+
+// A GROUP of weight gradients in one launch (mdm_wgrad_group_*): the weight gradients are leaves of the backward
+// pass -- they only read dY and the layer input, both of which stay in memory -- so they need not run where autograd
+// would put them.  The host collects the descriptors of a whole stretch of the backward, cuts every contraction
+// into work items of similar length (output tile x filter tap x k-range), sorts them longest first and launches
+// them as ONE flat grid: the chip is filled by the group, not by each layer on its own, so a layer needs only as
+// many k-splits as balance asks for (fewer fp32 partial slabs: the per-layer launches wrote and re-read ~0.9 GB
+// of them per step at cfg2), and ~70 launch gaps / prologues / drain tails per step disappear.
+// items[i] = {descriptor index, item index inside it, tiles per (tap, k-range), 1 = 128x128 tile / 0 = 64x64}.
+__global__ __launch_bounds__(512) void wgrad_group_kernel(const mdm_gemm_desc* descs, const int4* items) {
+    const int4 it = items[blockIdx.x];
+    const mdm_gemm_desc d = descs[it.x];
+    if (it.w) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
+    else wgrad_lin_body<64, 64, 4, 8>(d, it.y, it.z);
 }
 
 // ----------------------------------------------------------------------------
@@ -2023,7 +1893,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         const int il = (int)(((unsigned)hr * rcp_hri) >> 20), hrem = hr - il * HRI;
         const int hy = (int)(((unsigned)hrem * rcp_hw2) >> 20), hx = hrem - hy * HW2;
         const int y = y0 - 1 + hy, x = hx - 1;
-        const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M && !(d._p0 & 1);
+        const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M;
         // folded nearest x2 upsample (unet6.py:472): the map the conv sees is virtual, pixel (y, x) lives at (y>>1, x>>1)
         apix[k] = ok ? (((img + il) * (OH >> d.ups) + (y >> d.ups)) * (OW >> d.ups) + (x >> d.ups)) : -1;
     }
@@ -2043,7 +1913,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)bn * d.ldb) + lch16;
     auto issue_b = [&](int tap, int cs, int lds_off) {               // lds_off: byte offset of the tile inside the ring
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * 64) * 2;
-        lds_dma16((cs < NCS && b_wave && !(d._p0 & 2)) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
+        lds_dma16((cs < NCS && b_wave) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
     };
 
     // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..D-1 (in flight while the offset tables below are built)
@@ -2183,7 +2053,6 @@ static int validate(const mdm_gemm_desc& d) {
         } else {
             MDM_REQUIRE(d.A != nullptr && d.N == d.C0 + d.C1, "gemm: wgrad N=%d must equal C0+C1", d.N);
         }
-        if (d.layout == 0 || d.layout == 1) MDM_REQUIRE(!d.transposed || d.layout == 1 || d.layout == 0, "gemm");
     } else {
         MDM_REQUIRE(d.A != nullptr && d.B != nullptr, "gemm: missing operand");
         MDM_REQUIRE(d.lda % vec == 0 && d.ldb % vec == 0, "gemm: operand pitch must be a multiple of %d", vec);
@@ -2198,89 +2067,56 @@ static int validate(const mdm_gemm_desc& d) {
     return 0;
 }
 
-template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV, int NW>
+// ---- one dispatch rule, no run-time switches (measured alternatives are named in the comments of the kernels)
+constexpr int kBigMinTiles = 200;      // a tile shape is used when it still yields about one workgroup per CU
+constexpr int kWgradBlocks = 256;      // per-layer weight-gradient launch (mdm_gemm): aim at this many workgroups
+constexpr int kWgradMinSlabs = 4;      // ... of at least this many 64-deep k-slabs each
+
+template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV>
 static int launch_ring_one(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
     static bool configured = false;
     if (!configured) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV, NW>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV, NW>), grid, dim3(64 * NW), bytes, s, d);
+    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, LAYOUT, NSTAGE, CONV, 8>), grid, dim3(512), bytes, s, d);
     return 0;
 }
-template <int BM, int BN, int NSTAGE, int NW = 4>
+template <int BM, int BN, int NSTAGE>
 static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     const bool c = d.conv != 0;
     switch (d.layout) {
-        case 0: return c ? launch_ring_one<BM, BN, 0, NSTAGE, true, NW>(d, grid, s) : launch_ring_one<BM, BN, 0, NSTAGE, false, NW>(d, grid, s);
-        case 1: return c ? launch_ring_one<BM, BN, 1, NSTAGE, true, NW>(d, grid, s) : launch_ring_one<BM, BN, 1, NSTAGE, false, NW>(d, grid, s);
-        default: return c ? launch_ring_one<BM, BN, 2, NSTAGE, true, NW>(d, grid, s) : launch_ring_one<BM, BN, 2, NSTAGE, false, NW>(d, grid, s);
+        case 0: return c ? launch_ring_one<BM, BN, 0, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 0, NSTAGE, false>(d, grid, s);
+        case 1: return c ? launch_ring_one<BM, BN, 1, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 1, NSTAGE, false>(d, grid, s);
+        default: return c ? launch_ring_one<BM, BN, 2, NSTAGE, true>(d, grid, s) : launch_ring_one<BM, BN, 2, NSTAGE, false>(d, grid, s);
     }
 }
 
-template <int BM, int BN, int NSTAGE, int NW>
-static int launch_lin(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+template <int BM, int BN, int NSTAGE, int WR, int WC>
+static int launch_lin2(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {         // the software-pipelined variant
     constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
     static bool configured = false;
     if (!configured) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lin_kernel<BM, BN, NSTAGE, NW>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, 1, true, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((conv_lin_kernel<BM, BN, NSTAGE, NW>), grid, dim3(64 * NW), bytes, s, d);
+    hipLaunchKernelGGL((conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, 1, true, false>), grid, dim3(64 * WR * WC), bytes, s, d);
     return 0;
 }
-
-template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false>
-static int launch_lin2(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
-    constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
-    static_assert(WK == 1 || (BM * BN * 4) / WK <= bytes, "reduction scratch must fit the ring");
-    static bool configured = false;
-    if (!configured) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, WK, PIPE, STAG>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        configured = true;
-    }
-    hipLaunchKernelGGL((conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, WK, PIPE, STAG>), grid, dim3(64 * WR * WC * WK), bytes, s, d);
-    return 0;
-}
-
-struct PendingWgrad { mdm_gemm_desc d; int tiles_x, items; bool big; };
-static thread_local std::vector<PendingWgrad> g_pending_wgrad;
 
 template <int BM, int BN, int NSTAGE, int NW>
-static int launch_wgrad_lin(const PendingWgrad* a, const PendingWgrad* b, hipStream_t s) {
+static int launch_wgrad_lin(const mdm_gemm_desc& d, int tiles_x, int items, hipStream_t s) {
     constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
     static bool configured = false;
     if (!configured) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lin_kernel<BM, BN, NSTAGE, NW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_lin_pair_kernel<BM, BN, NSTAGE, NW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    if (b)
-        hipLaunchKernelGGL((wgrad_lin_pair_kernel<BM, BN, NSTAGE, NW>), dim3((unsigned)(a->items + b->items)), dim3(64 * NW), bytes, s,
-                           a->d, a->tiles_x, a->items, b->d, b->tiles_x);
-    else
-        hipLaunchKernelGGL((wgrad_lin_kernel<BM, BN, NSTAGE, NW>), dim3((unsigned)a->items), dim3(64 * NW), bytes, s, a->d, a->tiles_x);
-    return 0;
-}
-static int launch_wgrad(const PendingWgrad* a, const PendingWgrad* b, hipStream_t s) {
-    return a->big ? launch_wgrad_lin<128, 128, 3, 8>(a, b, s) : launch_wgrad_lin<64, 64, 4, 8>(a, b, s);
-}
-// launches every queued weight gradient (pairs of the same tile variant share a launch)
-int flush_wgrad(hipStream_t s) {
-    size_t i = 0;
-    while (i < g_pending_wgrad.size()) {
-        const PendingWgrad* a = &g_pending_wgrad[i];
-        const PendingWgrad* b = (i + 1 < g_pending_wgrad.size() && g_pending_wgrad[i + 1].big == a->big) ? &g_pending_wgrad[i + 1] : nullptr;
-        if (int rc = launch_wgrad(a, b, s)) { g_pending_wgrad.clear(); return rc; }
-        i += b ? 2 : 1;
-    }
-    g_pending_wgrad.clear();
+    hipLaunchKernelGGL((wgrad_lin_kernel<BM, BN, NSTAGE, NW>), dim3((unsigned)items), dim3(64 * NW), bytes, s, d, tiles_x);
     return 0;
 }
 static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
@@ -2291,13 +2127,13 @@ static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
     return d.stride == 1 && d.ups == 1 && ((64 / d.OW) & 1) == 0;                   // folded nearest x2 upsample
 }
 
-static int g_halo_small = []() { const char* e = getenv("MDM_HALO_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
 static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of one halo buffer
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
-static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
+template <int BM, int NPW, int NSB>
+static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filter row (3 taps) per barrier
+    constexpr int BN = 64, TG = 3;
     const int NPA = halo_pieces(BM, d.OH, d.OW);
     int bytes = 2 * NPA * 1024 + NSB * TG * BN * 128 + 1024;
     if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
@@ -2314,7 +2150,7 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
-static int halo_tile(const mdm_gemm_desc& d, int min_tiles) {
+static int halo_tile(const mdm_gemm_desc& d) {
     if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && (d.ups == 0 || d.ups == 1) &&
           !(d.ups && (d.transposed || d.C1)) && d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW &&
           d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && !d.out_f32))
@@ -2323,7 +2159,7 @@ static int halo_tile(const mdm_gemm_desc& d, int min_tiles) {
         for (int bm : {256, 128}) {
             if (bm % d.OW || d.OH % (bm / d.OW) || d.M % bm) continue;
             if (halo_pieces(bm, d.OH, d.OW) > 48) continue;
-            if ((int64_t)(d.M / bm) * (d.N / 64) >= min_tiles) return bm;
+            if ((int64_t)(d.M / bm) * (d.N / 64) >= kBigMinTiles) return bm;
         }
         return 0;
     }
@@ -2331,8 +2167,7 @@ static int halo_tile(const mdm_gemm_desc& d, int min_tiles) {
     // time is set by the filter bytes it streams (64 channels x 9 C: the same for every tile size), one launch
     // replaces the tap-split conv + its epilogue launch, and the tile holds whole images (GroupNorm-fusable)
     // (4x4 maps with > 256 input channels: 9 C x 64 filter bytes per workgroup outweigh the saved launch -- 17.1 vs 14.4 us)
-    if (g_halo_small && (d.OW == 4 || d.OW == 8) && d.OH == d.OW && 64 % (d.OH * d.OW) == 0 && d.M % 64 == 0 &&
-        !(d.OW == 4 && d.Ck > 256)) return 64;
+    if ((d.OW == 4 || d.OW == 8) && d.OH == d.OW && 64 % (d.OH * d.OW) == 0 && d.M % 64 == 0 && !(d.OW == 4 && d.Ck > 256)) return 64;
     return 0;
 }
 
@@ -2353,87 +2188,49 @@ static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     }
 }
 
-static int g_use_ring = []() { const char* e = getenv("MDM_NO_RING"); return (e && e[0] == '1') ? 0 : 1; }();
-static int g_force_small = []() { const char* e = getenv("MDM_FORCE_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
-static int g_wgrad_small = []() { const char* e = getenv("MDM_WGRAD_SMALL"); return (e && e[0] == '1') ? 1 : 0; }();
-static int g_wgrad_big_min = []() { const char* e = getenv("MDM_WGRAD_BIG_MIN"); return e ? atoi(e) : 1; }();
-static int g_wgrad_min_slabs = []() { const char* e = getenv("MDM_WGRAD_MIN_SLABS"); return e ? atoi(e) : 4; }();
-static int g_wgrad_blocks = []() { const char* e = getenv("MDM_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }();
-static int g_big_waves = []() { const char* e = getenv("MDM_BIG_WAVES"); return e ? atoi(e) : 8; }();
-static int g_lin_tile = []() { const char* e = getenv("MDM_LIN_TILE"); return e ? atoi(e) : 0; }();
-static int g_dbg_flags = []() { const char* e = getenv("MDM_DBG_FLAGS"); return e ? atoi(e) : 0; }();
-static int g_use_lin = []() { const char* e = getenv("MDM_NO_LIN"); return (e && e[0] == '1') ? 0 : 1; }();
-static int g_tap_split = []() { const char* e = getenv("MDM_TAP_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_big_min_tiles = []() { const char* e = getenv("MDM_BIG_MIN_TILES"); return e ? atoi(e) : 200; }();
-static int g_small_waves = []() { const char* e = getenv("MDM_SMALL_WAVES"); return e ? atoi(e) : 8; }();
-static int g_big_stages = []() { const char* e = getenv("MDM_BIG_STAGES"); return e ? atoi(e) : 3; }();
-static int g_stages64 = []() { const char* e = getenv("MDM_STAGES64"); return e ? atoi(e) : 4; }();
-static int g_halo_tg = []() { const char* e = getenv("MDM_HALO_TG"); return e ? atoi(e) : 3; }();
-static int g_halo = []() { const char* e = getenv("MDM_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_wgrad_lin = []() { const char* e = getenv("MDM_WGRAD_LIN"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_lin2 = []() { const char* e = getenv("MDM_LIN2"); return e ? atoi(e) : 3; }();   // 0: conv_lin_kernel, 1: lin2, 2: lin2 with k-split wave pairs, 3: lin2 pipelined (default), 4: pipelined + staggered wave groups
-
 }  // namespace mdm
 extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G);
 extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G);
 namespace mdm {
-static thread_local std::vector<ReduceSeg> g_pending;
 
-int flush_wgrad(hipStream_t s);
-int reduce_pending(hipStream_t s) {
-    if (int rc = flush_wgrad(s)) return rc;      // the partials must exist before they are summed
-    size_t i = 0;
-    while (i < g_pending.size()) {
-        ReduceTable tab;
-        tab.n = 0;
-        int blocks = 0;
-        while (i < g_pending.size() && tab.n < REDUCE_MAX_SEGS) {
-            const ReduceSeg& sg = g_pending[i];
-            const long long nb = (sg.total4 + REDUCE_VEC_PER_BLOCK - 1) / REDUCE_VEC_PER_BLOCK;
-            if (blocks + nb > (1ll << 30)) break;
-            tab.first_block[tab.n] = blocks;
-            tab.seg[tab.n++] = sg;
-            blocks += (int)nb;
-            ++i;
-        }
-        tab.first_block[tab.n] = blocks;
-        if (blocks > 0) hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, tab);
-    }
-    g_pending.clear();
-    return launch_status("splitk reduce (batched)");
-}
-
-int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullptr, int64_t* plan_ws = nullptr) {
+// What mdm_gemm decides before it launches: the tile family, the reduction split, where split-K partials go.
+struct Resolved {
+    mdm_gemm_desc d;
+    bool big, tap_split;
+    int zouter;
+    int64_t tiles, slab;        // output tiles of the chosen shape; bytes of one dense fp32 copy of the output
+};
+static int resolve(const mdm_gemm_desc* dh, bool planning, Resolved& r) {
     MDM_REQUIRE(dh != nullptr, "gemm: null descriptor");
-    mdm_gemm_desc d = *dh;
-    if (plan_splitk) { d.ws = reinterpret_cast<void*>(16); d.ws_bytes = (int64_t)1 << 60; }   // "unlimited": never dereferenced
+    mdm_gemm_desc& d = r.d;
+    d = *dh;
+    if (planning) { d.ws = reinterpret_cast<void*>(16); d.ws_bytes = (int64_t)1 << 60; }   // "unlimited": never dereferenced
     if (d.N0 == 0) d.N0 = d.N;
-    d._p0 = g_dbg_flags;        // timing experiments only (bit 0: A operand from the zero page, bit 1: B operand)
     if (int rc = validate(d)) return rc;
-    int zouter = d.batch;
-    if (d.layout == 2 && d.conv) zouter = d.KH * d.KW;
+    r.zouter = d.batch;
+    if (d.layout == 2 && d.conv) r.zouter = d.KH * d.KW;
     // tile choice: 128x128 when that still yields enough workgroups; weight gradients (layout 2: small
     // output, huge reduction, split-K supplies the parallelism) take the big tile whenever it fits.
-    const bool big = d.dtype == MDM_BF16 && !g_force_small && d.N >= 128 && d.M >= 128 &&
-                     (d.layout == 2 ? (!g_wgrad_small && d.K >= 2048 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= g_wgrad_big_min) : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zouter >= g_big_min_tiles);
-    const int BM = d.dtype == MDM_F32 ? 64 : (big ? 128 : 64), BN = BM;
+    r.big = d.dtype == MDM_BF16 && d.N >= 128 && d.M >= 128 &&
+            (d.layout == 2 ? d.K >= 2048 : (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * r.zouter >= kBigMinTiles);
+    const int BM = d.dtype == MDM_F32 ? 64 : (r.big ? 128 : 64), BN = BM;
     const int BK = d.dtype == MDM_F32 ? 16 : 64;
-    int64_t tiles = (int64_t)cdiv(d.M, BM) * cdiv(d.N, BN);
+    r.tiles = (int64_t)cdiv(d.M, BM) * cdiv(d.N, BN);
     if (d.layout == 2) {
-        if (d.splitk <= 0) {     // auto: aim at ~g_wgrad_blocks workgroups, at least 4 k-steps each
-            int64_t want = (big ? g_wgrad_blocks : 4 * g_wgrad_blocks) / (tiles * zouter);
-            int64_t cap = d.K / (g_wgrad_min_slabs * BK);
+        if (d.splitk <= 0) {     // auto: aim at ~kWgradBlocks workgroups, at least kWgradMinSlabs k-steps each
+            int64_t want = (r.big ? kWgradBlocks : 4 * kWgradBlocks) / (r.tiles * r.zouter);
+            int64_t cap = d.K / (kWgradMinSlabs * BK);
             d.splitk = (int)(want < 1 ? 1 : (want > cap ? (cap < 1 ? 1 : cap) : want));
-            if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
         }
+        if (d.splitk > 1 && !(d.out_f32 || d.dtype == MDM_F32)) d.splitk = 1;
     } else if (d.conv) {
         // small-M forward / data gradient: too few tiles to fill the chip -> split the filter taps over grid z
         d.splitk = 1;
         const int taps = d.KH * d.KW;
-        if (g_halo && halo_tile(d, g_big_min_tiles) == 64) {
+        if (halo_tile(d) == 64) {
             /* single launch on the halo kernel: no tap split */
-        } else if (g_tap_split && d.ws && d.dtype == MDM_BF16 && ring_eligible(d) && taps >= 9 && taps % 3 == 0 && tiles <= 160) {
-            int sk = tiles <= 48 ? taps : 3;
+        } else if (d.ws && d.dtype == MDM_BF16 && ring_eligible(d) && taps >= 9 && taps % 3 == 0 && r.tiles <= 160) {
+            int sk = r.tiles <= 48 ? taps : 3;
             if (taps % sk) sk = 3;
             if (d.ws_bytes >= (int64_t)sk * d.M * d.N * 4) d.splitk = sk;
         }
@@ -2441,31 +2238,35 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
         d.splitk = 1;
     }
     // slab mode needs a dense fp32 [tap|batch][M][N] destination and room for every split
-    const bool tap_split = d.conv && d.layout != 2 && d.splitk > 1;
+    r.tap_split = d.conv && d.layout != 2 && d.splitk > 1;
     const bool dense = d.out_f32 && d.N0 == d.N && d.ldd0 == d.N &&
-                       (d.layout == 2 && d.conv ? d.dtap == (int64_t)d.M * d.N : (zouter == 1 || d.sD == (int64_t)d.M * d.N));
-    const int64_t slab = (int64_t)zouter * d.M * d.N * 4;
-    if (tap_split) {
+                       (d.layout == 2 && d.conv ? d.dtap == (int64_t)d.M * d.N : (r.zouter == 1 || d.sD == (int64_t)d.M * d.N));
+    r.slab = (int64_t)r.zouter * d.M * d.N * 4;
+    if (r.tap_split) {
         /* workspace size checked above */
-    } else if (d.splitk > 1 && d.ws && dense && d.ws_bytes >= slab * 2) {
-        if (d.ws_bytes < slab * d.splitk) d.splitk = (int)(d.ws_bytes / slab);
+    } else if (d.splitk > 1 && d.ws && dense && d.ws_bytes >= r.slab * 2) {
+        if (d.ws_bytes < r.slab * d.splitk) d.splitk = (int)(d.ws_bytes / r.slab);
     } else {
         d.ws = nullptr;
     }
-    if (d.gnb_x && !plan_splitk)
+    return 0;
+}
+
+static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
+    Resolved r;
+    if (int rc = resolve(dh, false, r)) return rc;
+    const mdm_gemm_desc& d = r.d;
+    const bool big = r.big;
+    if (d.gnb_x)
         MDM_REQUIRE(mdm_gemm_can_fuse_gn_bwd(&d, d.gnb_G) == 1 && d.gnb_stats && d.gnb_gamma && d.gnb_beta && d.gnb_dgamma && d.gnb_dbeta,
                     "gemm: gnb_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_bwd)");
-    if (d.gnf_out && !plan_splitk)
+    if (d.gnf_out)
         MDM_REQUIRE(mdm_gemm_can_fuse_gn_fwd(&d, d.gnf_G) == 1 && d.gnf_gamma && d.gnf_beta && d.gnf_stats,
                     "gemm: gnf_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_fwd)");
-    if (plan_splitk) {
-        *plan_splitk = d.splitk;
-        *plan_ws = (d.ws && d.splitk > 1) ? (tap_split ? (int64_t)d.splitk * d.M * d.N * 4 : slab * d.splitk) : 0;
-        return 0;
-    }
-    MDM_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
-    dim3 grid((unsigned)tiles, 1, (unsigned)(zouter * d.splitk));
+    MDM_REQUIRE(r.tiles < (1ll << 31), "gemm: grid too large");
+    dim3 grid((unsigned)r.tiles, 1, (unsigned)(r.zouter * d.splitk));
     MDM_REQUIRE(grid.z <= 65535, "gemm: grid.z=%u too large", grid.z);
+    int rc = 0;
     if (d.dtype == MDM_F32 && d.layout == 0 && !d.conv && d.M <= 32 && d.K % 64 == 0 && d.K <= 512 && d.splitk <= 1 &&
         d.batch == 1 && !d.rowvec && !d.resid && !d.acc0 && d.N0 == d.N && d.lda % 4 == 0 && d.ldb % 4 == 0) {
         static bool configured = false;
@@ -2482,70 +2283,44 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
             case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
             default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
         }
-    } else if (g_use_ring && g_use_lin && ring_eligible(d) && d.layout == 0 && d.conv &&
-               (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0 && g_lin2 == 3 && d.C0 <= 4096 && d.C1 <= 4096)) &&
-               (d.ups == 0 || (g_halo && d.splitk <= 1 && halo_tile(d, g_big_min_tiles) != 0)) &&
-               d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
+    } else if (ring_eligible(d) && d.layout == 0 && d.conv &&
+               (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0)) && d.C0 <= 4096 && d.C1 <= 4096 &&
+               (d.ups == 0 || (d.splitk <= 1 && halo_tile(d) != 0)) && d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
         // tile choice (measured per shape): the largest tile that still gives the chip ~one workgroup per CU --
         // 128x128 for the 32x32 maps, 64x128 for the 16x16 maps (+20 % over 64x64), 64x64 below that
-        int rc;
         const int64_t t_mid = (int64_t)cdiv(d.M, 64) * cdiv(d.N, 128) * grid.z;
-        const bool lin2 = g_lin2 && d.C0 <= 4096 && d.C1 <= 4096;     // a segment walks <= 8 KiB inside the zero page
-        const int hb = (g_halo && d.splitk <= 1) ? halo_tile(d, g_big_min_tiles) : 0;
+        const int hb = d.splitk <= 1 ? halo_tile(d) : 0;
         if (hb) {
             const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
-            if (g_halo_tg == 3)          // one filter row per barrier
-                rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 64, 2, 3>(d, s) : launch_halo<256, 6, 64, 2, 3>(d, s))
-                     : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 64, 2, 3>(d, s) : npw <= 4 ? launch_halo<128, 4, 64, 2, 3>(d, s) : launch_halo<128, 6, 64, 2, 3>(d, s))
-                                 : (npw <= 2 ? launch_halo<64, 2, 64, 3, 3>(d, s) : launch_halo<64, 3, 64, 3, 3>(d, s));
-            else
-                rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4>(d, s) : launch_halo<256, 6>(d, s))
-                     : hb == 128 ? (npw <= 3 ? launch_halo<128, 3>(d, s) : npw <= 4 ? launch_halo<128, 4>(d, s) : launch_halo<128, 6>(d, s))
-                                 : (npw <= 2 ? launch_halo<64, 2>(d, s) : launch_halo<64, 3>(d, s));
+            rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 2>(d, s) : launch_halo<256, 6, 2>(d, s))
+                 : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 2>(d, s) : npw <= 4 ? launch_halo<128, 4, 2>(d, s) : launch_halo<128, 6, 2>(d, s))
+                             : (npw <= 2 ? launch_halo<64, 2, 3>(d, s) : launch_halo<64, 3, 3>(d, s));
         } else if (big) {
-            rc = !lin2 ? launch_lin<128, 128, 3, 8>(d, grid, s)
-                 : g_lin2 == 2 ? launch_lin2<128, 128, 3, 2, 2, 2>(d, grid, s)
-                 : g_lin2 == 4 ? launch_lin2<128, 128, 4, 4, 2, 1, true, true>(d, grid, s)
-                 : g_lin2 == 3 ? launch_lin2<128, 128, 3, 4, 2, 1, true>(d, grid, s) : launch_lin2<128, 128, 3, 4, 2, 1>(d, grid, s);
-        } else if (!g_force_small && d.N >= 128 && t_mid >= g_big_min_tiles && g_lin_tile != 9) {
+            rc = launch_lin2<128, 128, 3, 4, 2>(d, grid, s);
+        } else if (d.N >= 128 && t_mid >= kBigMinTiles) {
             dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
-            rc = !lin2 ? launch_lin<64, 128, 3, 8>(d, g2, s)
-                 : g_lin2 == 2 ? launch_lin2<64, 128, 3, 1, 4, 2>(d, g2, s)
-                 : g_lin2 == 4 ? launch_lin2<64, 128, 4, 2, 4, 1, true, true>(d, g2, s)
-                 : g_lin2 == 3 ? launch_lin2<64, 128, 3, 2, 4, 1, true>(d, g2, s) : launch_lin2<64, 128, 3, 2, 4, 1>(d, g2, s);
+            rc = launch_lin2<64, 128, 3, 2, 4>(d, g2, s);
         } else {
-            rc = !lin2 ? launch_lin<64, 64, 4, 8>(d, grid, s)
-                 : g_lin2 == 2 ? launch_lin2<64, 64, 4, 2, 2, 2>(d, grid, s)
-                 : g_lin2 == 4 ? launch_lin2<64, 64, 4, 4, 2, 1, true, true>(d, grid, s)
-                 : g_lin2 == 3 ? launch_lin2<64, 64, 4, 4, 2, 1, true>(d, grid, s) : launch_lin2<64, 64, 4, 4, 2, 1>(d, grid, s);
+            rc = launch_lin2<64, 64, 4, 4, 2>(d, grid, s);
         }
-        if (rc) return rc;
-    } else if (g_use_ring && g_wgrad_lin && wgrad_lin_eligible(d)) {
+    } else if (wgrad_lin_eligible(d)) {
         MDM_REQUIRE((int64_t)grid.x * grid.z < (1ll << 30), "gemm: grid too large");
-        g_pending_wgrad.push_back(PendingWgrad{d, (int)grid.x, (int)(grid.x * grid.z), big});
-        // defer_launch: wait for the next weight gradient (or any flush) and share its launch
-        if (!(d.defer_launch && d.splitk > 1 && d.ws && d.defer_reduce && g_pending_wgrad.size() < 2))
-            if (int rc = flush_wgrad(s)) return rc;
-    } else if (g_use_ring && ring_eligible(d)) {
-        int rc = big ? (g_big_waves == 16 ? launch_ring<128, 128, 3, 16>(d, grid, s) : g_big_waves == 8 ? (g_big_stages == 4 ? launch_ring<128, 128, 4, 8>(d, grid, s) : launch_ring<128, 128, 3, 8>(d, grid, s))
-                                         : launch_ring<128, 128, 3>(d, grid, s))
-                     : (g_small_waves == 8 ? launch_ring<64, 64, 4, 8>(d, grid, s)
-                        : (g_stages64 == 3 ? launch_ring<64, 64, 3>(d, grid, s) : launch_ring<64, 64, 4>(d, grid, s)));
-        if (rc) return rc;
+        rc = big ? launch_wgrad_lin<128, 128, 3, 8>(d, (int)grid.x, (int)(grid.x * grid.z), s)
+                 : launch_wgrad_lin<64, 64, 4, 8>(d, (int)grid.x, (int)(grid.x * grid.z), s);
+    } else if (ring_eligible(d)) {
+        rc = big ? launch_ring<128, 128, 3>(d, grid, s) : launch_ring<64, 64, 4>(d, grid, s);
     } else if (big) {
         launch_bf16<128, 128>(d, grid, s);
     } else {
         launch_bf16<64, 64>(d, grid, s);
     }
-    if (tap_split) {
+    if (rc) return rc;
+    if (r.tap_split) {
         const int64_t total4 = (int64_t)d.M * d.N / 4;
         int64_t nb = (total4 + 255) / 256;
         hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t>), dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s, d);
-    } else if (d.splitk > 1 && d.ws && d.defer_reduce) {
-        g_pending.push_back(ReduceSeg{reinterpret_cast<const float*>(d.ws), reinterpret_cast<float*>(d.D0),
-                                      (long long)((int64_t)zouter * d.M * d.N / 4), d.splitk, d.acc0});
     } else if (d.splitk > 1 && d.ws) {
-        const int64_t total4 = (int64_t)zouter * d.M * d.N / 4;
+        const int64_t total4 = (int64_t)r.zouter * d.M * d.N / 4;
         int64_t nb = (total4 + 255) / 256;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s,
                            reinterpret_cast<const float*>(d.ws), d.splitk, total4, reinterpret_cast<float*>(d.D0), d.acc0);
@@ -2553,7 +2328,131 @@ int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s, int* plan_splitk = nullp
     return launch_status("gemm launch");
 }
 
+// ---- grouped weight gradients ---------------------------------------------------------------------------------
+struct WgradGroup {
+    const mdm_gemm_desc* descs_dev = nullptr;
+    const int4* items_dev = nullptr;
+    int n_items = 0;
+    std::vector<ReduceTable> reduces;       // the split-K sums of the group's split layers: passed by value at launch
+    std::vector<int> reduce_blocks;
+};
+struct GroupItem { int desc, item, tiles_x, big, cost; };
+
 }  // namespace mdm
+using namespace mdm;
+
+extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
+    return gemm_launch(desc_host, pick_stream(stream));
+}
+extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
+    if (!desc_host || G <= 0) return 0;
+    mdm_gemm_desc d = *desc_host;
+    if (d.N0 == 0) d.N0 = d.N;
+    if (!(d.transposed && d.N % G == 0 && d.N0 == d.N && d.C1 == 0 && !d.D1 && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f)) return 0;
+    const int cpg = d.N / G;
+    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
+    return halo_tile(d) == 64 ? 1 : 0;
+}
+extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G) {
+    if (!desc_host || G <= 0) return 0;
+    mdm_gemm_desc d = *desc_host;
+    if (d.N0 == 0) d.N0 = d.N;
+    if (!(!d.transposed && d.N % G == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.acc0 && d.ldd0 == d.N)) return 0;
+    const int cpg = d.N / G;
+    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
+    return halo_tile(d) == 64 ? 1 : 0;
+}
+extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
+    if (!splitk_out || !ws_bytes_out) { set_error("gemm_plan: null output"); return -1; }
+    Resolved r;
+    if (int rc = resolve(desc_host, true, r)) return rc;
+    *splitk_out = r.d.splitk;
+    *ws_bytes_out = (r.d.ws && r.d.splitk > 1) ? (r.tap_split ? (int64_t)r.d.splitk * r.d.M * r.d.N * 4 : r.slab * r.d.splitk) : 0;
+    return 0;
+}
+
+extern "C" int mdm_wgrad_group_accepts(const mdm_gemm_desc* desc_host) {
+    if (!desc_host) return 0;
+    mdm_gemm_desc d = *desc_host;
+    if (d.N0 == 0) d.N0 = d.N;
+    return wgrad_lin_eligible(d) && d.out_f32 && d.N0 == d.N && d.ldd0 == d.N && d.dtap == (int64_t)d.M * d.N ? 1 : 0;
+}
+extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, void* dev_buf, int64_t dev_bytes,
+                                      int64_t* need_bytes_out, void** handle_out) {
+    MDM_REQUIRE(descs_host && n > 0 && need_bytes_out && handle_out, "wgrad_group_create: bad arguments");
+    *handle_out = nullptr;
+    std::vector<mdm_gemm_desc> ds((size_t)n);
+    std::vector<GroupItem> items;
+    WgradGroup* g = new WgradGroup();
+    ReduceTable tab;
+    tab.n = 0;
+    int blocks = 0;
+    auto close_table = [&]() {
+        if (tab.n > 0) { tab.first_block[tab.n] = blocks; g->reduces.push_back(tab); g->reduce_blocks.push_back(blocks); }
+        tab.n = 0; blocks = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+        Resolved r;
+        if (int rc = resolve(descs_host + i, false, r)) { delete g; return rc; }
+        if (!mdm_wgrad_group_accepts(&r.d)) { delete g; set_error("wgrad_group_create: descriptor %d is not a groupable weight gradient", i); return -1; }
+        if (r.d.splitk > 1 && !r.d.ws) { delete g; set_error("wgrad_group_create: descriptor %d is split %d ways but has no workspace of its own", i, r.d.splitk); return -1; }
+        ds[(size_t)i] = r.d;
+        const mdm_gemm_desc& d = r.d;
+        const int BK = 64, sk = d.splitk < 1 ? 1 : d.splitk;
+        const int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
+        const int n_local = (int)(r.tiles * r.zouter * sk);
+        for (int it = 0; it < n_local; ++it) {
+            const int ks = it / (int)(r.tiles * r.zouter);
+            int len = d.K - ks * chunk;
+            if (len > chunk) len = chunk;
+            items.push_back(GroupItem{i, it, (int)r.tiles, r.big ? 1 : 0, (len / BK) * (r.big ? 4 : 1) + 2});
+        }
+        if (sk > 1) {
+            const long long total4 = (long long)((int64_t)r.zouter * d.M * d.N / 4);
+            const long long nb = (total4 + REDUCE_VEC_PER_BLOCK - 1) / REDUCE_VEC_PER_BLOCK;
+            if (tab.n == REDUCE_MAX_SEGS || blocks + nb > (1ll << 30)) close_table();
+            tab.first_block[tab.n] = blocks;
+            tab.seg[tab.n++] = ReduceSeg{reinterpret_cast<const float*>(d.ws), reinterpret_cast<float*>(d.D0), total4, sk, d.acc0};
+            blocks += (int)nb;
+        }
+    }
+    close_table();
+    // longest items first: the short ones fill the tail of the launch
+    std::stable_sort(items.begin(), items.end(), [](const GroupItem& a, const GroupItem& b) { return a.cost > b.cost; });
+    const int64_t desc_bytes = ((int64_t)n * (int64_t)sizeof(mdm_gemm_desc) + 255) / 256 * 256;
+    const int64_t need = desc_bytes + (int64_t)items.size() * 16;
+    *need_bytes_out = need;
+    if (!dev_buf || dev_bytes < need) { delete g; return 0; }      // size query
+    std::vector<int4> it4(items.size());
+    for (size_t i = 0; i < items.size(); ++i) it4[i] = make_int4(items[i].desc, items[i].item, items[i].tiles_x, items[i].big);
+    hipError_t e = hipMemcpy(dev_buf, ds.data(), (size_t)n * sizeof(mdm_gemm_desc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(dev_buf) + desc_bytes, it4.data(), it4.size() * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete g; return hip_fail(e, "wgrad_group_create: hipMemcpy"); }
+    g->descs_dev = reinterpret_cast<const mdm_gemm_desc*>(dev_buf);
+    g->items_dev = reinterpret_cast<const int4*>(reinterpret_cast<char*>(dev_buf) + desc_bytes);
+    g->n_items = (int)items.size();
+    *handle_out = g;
+    return 0;
+}
+extern "C" int mdm_wgrad_group_launch(void* handle, void* stream) {
+    MDM_REQUIRE(handle, "wgrad_group_launch: null handle");
+    const WgradGroup* g = reinterpret_cast<const WgradGroup*>(handle);
+    hipStream_t s = pick_stream(stream);
+    constexpr int bytes = 3 * (128 + 128) * 64 * 2;        // the larger of the two rings (64x64: 4 stages of 16 KiB)
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)g->n_items), dim3(512), bytes, s, g->descs_dev, g->items_dev);
+    for (size_t i = 0; i < g->reduces.size(); ++i)
+        hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)g->reduce_blocks[i]), dim3(256), 0, s, g->reduces[i]);
+    return launch_status("wgrad group");
+}
+extern "C" int mdm_wgrad_group_destroy(void* handle) {
+    delete reinterpret_cast<WgradGroup*>(handle);
+    return 0;
+}
 
 #ifdef MDM_STAMP
 extern "C" int mdm_debug_stamps(unsigned long long* out, int reset) {      // out: 4096 * 32 entries
@@ -2565,38 +2464,3 @@ extern "C" int mdm_debug_stamps(unsigned long long* out, int reset) {      // ou
     return 0;
 }
 #endif
-
-extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
-    return mdm::gemm_launch(desc_host, mdm::pick_stream(stream));
-}
-extern "C" int mdm_splitk_reduce_pending(void* stream) { return mdm::reduce_pending(mdm::pick_stream(stream)); }
-extern "C" int mdm_gemm_flush(void* stream) { return mdm::flush_wgrad(mdm::pick_stream(stream)); }
-extern "C" int mdm_gemm_discard_pending(void) {           // error recovery: forget every queued launch / reduction
-    mdm::g_pending_wgrad.clear();
-    mdm::g_pending.clear();
-    return 0;
-}
-extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
-    if (!desc_host || G <= 0) return 0;
-    mdm_gemm_desc d = *desc_host;
-    if (d.N0 == 0) d.N0 = d.N;
-    if (!mdm::g_halo || !mdm::g_use_ring || !mdm::g_use_lin || mdm::g_halo_tg != 3) return 0;
-    if (!(d.transposed && d.N % G == 0 && d.N0 == d.N && d.C1 == 0 && !d.D1 && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f)) return 0;
-    const int cpg = d.N / G;
-    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
-    return mdm::halo_tile(d, mdm::g_big_min_tiles) == 64 ? 1 : 0;
-}
-extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G) {
-    if (!desc_host || G <= 0) return 0;
-    mdm_gemm_desc d = *desc_host;
-    if (d.N0 == 0) d.N0 = d.N;
-    if (!mdm::g_halo || !mdm::g_use_ring || !mdm::g_use_lin || mdm::g_halo_tg != 3) return 0;
-    if (!(!d.transposed && d.N % G == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.acc0 && d.ldd0 == d.N)) return 0;
-    const int cpg = d.N / G;
-    if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
-    return mdm::halo_tile(d, mdm::g_big_min_tiles) == 64 ? 1 : 0;
-}
-extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
-    if (!splitk_out || !ws_bytes_out) { mdm::set_error("gemm_plan: null output"); return -1; }
-    return mdm::gemm_launch(desc_host, nullptr, splitk_out, ws_bytes_out);
-}

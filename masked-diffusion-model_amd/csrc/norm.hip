@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
                                                      const float* gamma, const float* beta, int silu, const T* dy,
-                                                     const float* stats, T* d0, int acc0, T* d1, int acc1,
+                                                     const float* stats, T* d0, const T* add0, T* d1, const T* add1,
                                                      float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
     const int C = C0 + C1, cpg = C / G;
     const int VB = CBLK / 8, PL = 256 / VB;
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
         __syncthreads();
     }
     if (on) {
-        T* dst; int acc, cc, CS;
-        if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
+        T* dst; const T* addp; int cc, CS;           // addp: a tensor laid out like dst whose values are added (dst itself = accumulate)
+        if (c < C0) { dst = d0; addp = add0; cc = c; CS = C0; } else { dst = d1; addp = add1; cc = c - C0; CS = C1; }
         float sx[8] = {};                     // column sums of dx (bias / time-embedding gradient of the producer conv)
         auto put = [&](int p, const float8& x, const float8& d) {
             float xv[8] = F8_TO_ARR(x);
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
                 sx[e] += o[e];
             }
             T* q = dst + (base + p) * CS + cc;
-            if (acc) {
-                float8 old = load8(q);
+            if (addp) {
+                float8 old = load8(addp + (base + p) * CS + cc);
                 float ov[8] = F8_TO_ARR(old);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] += ov[e];
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
 template <int NP, int MODE>
 __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          const float* gamma, const float* beta, int silu, const bf16_t* dy,
-                                                         const float* stats, bf16_t* d0, int acc0, bf16_t* d1, int acc1,
+                                                         const float* stats, bf16_t* d0, const bf16_t* add0, bf16_t* d1, const bf16_t* add1,
                                                          float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all,
                                                          float* ws) {
     const int C = C0 + C1, cpg = C / G;
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
     }
     float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (on) {
-        bf16_t* dst; int acc, cc, CS;
-        if (c < C0) { dst = d0; acc = acc0; cc = c; CS = C0; } else { dst = d1; acc = acc1; cc = c - C0; CS = C1; }
+        bf16_t* dst; const bf16_t* addp; int cc, CS;
+        if (c < C0) { dst = d0; addp = add0; cc = c; CS = C0; } else { dst = d1; addp = add1; cc = c - C0; CS = C1; }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             int p = pbeg + lane + i * PL;
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
                     sx[e] += o[e];
                 }
                 bf16_t* q = dst + (base + p) * CS + cc;
-                if (acc) {
-                    float8 old = load8(q);
+                if (addp) {
+                    float8 old = load8(addp + (base + p) * CS + cc);
                     float ov[8] = F8_TO_ARR(old);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += ov[e];
@@ -684,11 +684,14 @@ __global__ void nhwc_to_nchw_kernel(const T* x, float* y, int C, int HW, int Cp,
 }
 
 template <typename T>
-__global__ void add_kernel(T* dst, const T* src, int64_t nvec) {
+__global__ void add_kernel(T* dst, const T* x, const T* y, int64_t nvec) {       // dst = x + y (y == nullptr: copy)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        float8 a = load8(dst + i * 8), b = load8(src + i * 8);
-        a.lo.x += b.lo.x; a.lo.y += b.lo.y; a.lo.z += b.lo.z; a.lo.w += b.lo.w;
-        a.hi.x += b.hi.x; a.hi.y += b.hi.y; a.hi.z += b.hi.z; a.hi.w += b.hi.w;
+        float8 a = load8(x + i * 8);
+        if (y) {
+            float8 b = load8(y + i * 8);
+            a.lo.x += b.lo.x; a.lo.y += b.lo.y; a.lo.z += b.lo.z; a.lo.w += b.lo.w;
+            a.hi.x += b.hi.x; a.hi.y += b.hi.y; a.hi.z += b.hi.z; a.hi.w += b.hi.w;
+        }
         store8(dst + i * 8, a);
     }
 }
@@ -747,21 +750,18 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
 }
 
 // channels per workgroup: whole groups, whole 16-byte vectors, at least 32 channels
-static int g_gn_regs = []() { const char* e = getenv("MDM_GN_REGS"); return (e && e[0] == '0') ? 0 : 1; }();
-static int g_gn_minc = []() { const char* e = getenv("MDM_GN_MINC"); return e ? atoi(e) : 0; }();   // 0: by map size
-// pixel-chunked statistics + apply launches: measured no faster than the single launch at cfg2 (13.4 vs 13.7 us
-// forward, 25.3 vs 24.1 us backward on 32x32x128: two ~5 us launch floors eat the bandwidth gain) -> opt-in
-static int g_gn_split = []() { const char* e = getenv("MDM_GN_SPLIT"); return (e && e[0] == '1') ? 1 : 0; }();
 static int gn_cblk(int C, int G, int N, int P) {
     int cpg = C / G, l = cpg;
     while (l % 8) l += cpg;            // lcm(cpg, 8)
     // 32 channels per workgroup; 16 on large maps (more workgroups pulling HBM: 12.3 -> 10.1 us forward,
     // 21.0 -> 15.8 us backward on 32x32x128; slower on the small maps, where the launch floor dominates)
-    int want = g_gn_minc > 0 ? g_gn_minc : (P > 256 ? 16 : 32);
+    int want = P > 256 ? 16 : 32;
     int cb = l;
     while (cb < want) cb += l;
     return cb > C ? C : cb;
 }
+// (A pixel-chunked statistics + apply pair of launches -- MODE 1 / 2 of the register kernels -- was measured no faster
+// than the single launch at cfg2: 13.4 vs 13.7 us forward, 25.3 vs 24.1 us backward on 32x32x128; it is not dispatched.)
 extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                  float eps, const float* gamma, const float* beta, int silu, void* y, float* stats,
                                  float* ws, void* stream) {
@@ -770,16 +770,7 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     dim3 grid(N, cdiv(C, cblk));
     const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane
-    const int chunks = cdiv(np, 4);
-    if (dtype == MDM_BF16 && g_gn_regs && g_gn_split && ws && np > 4 && chunks <= 32 && (int64_t)grid.x * grid.y < 512) {
-        dim3 g3(grid.x, grid.y, chunks);                 // chunk length P/chunks <= 4 vectors per lane
-#define GN_FWD_SPLIT(M) hipLaunchKernelGGL((gn_fwd_reg_kernel<4, M>), g3, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
-                                           (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
-        GN_FWD_SPLIT(1); GN_FWD_SPLIT(2);
-#undef GN_FWD_SPLIT
-        return launch_status("groupnorm_fwd");
-    }
-    if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
+    if (dtype == MDM_BF16 && np <= 16) {
 #define GN_FWD_REG(NPV) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
                                            (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
         if (np <= 1) GN_FWD_REG(1); else if (np <= 2) GN_FWD_REG(2); else if (np <= 4) GN_FWD_REG(4);
@@ -792,10 +783,40 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     return launch_status("groupnorm_fwd");
 }
 
+extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
+                                     const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
+                                     void* dst0, const void* add0, void* dst1, const void* add1, float* dgamma, float* dbeta,
+                                     float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream) {
+    if (int rc = gn_check(C0, C1, G, N, P)) return rc;
+    const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
+    MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
+    MDM_REQUIRE(!(sum_img || sum_all) || C1 == 0, "groupnorm_bwd: column sums need a single-source dx");
+    dim3 grid(N, cdiv(C, cblk));
+    const int np = cdiv(P, 256 / (cblk / 8));
+    if (dtype == MDM_BF16 && np <= 16) {
+#define GN_BWD_REG(NPV) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                           (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
+                                           (bf16_t*)dst0, (const bf16_t*)add0, (bf16_t*)dst1, (const bf16_t*)add1, dgamma, dbeta,       \
+                                           sum_img, sum_ld, sum_all, ws)
+        if (np <= 1) GN_BWD_REG(1); else if (np <= 2) GN_BWD_REG(2); else if (np <= 4) GN_BWD_REG(4);
+        else if (np <= 8) GN_BWD_REG(8); else GN_BWD_REG(16);
+#undef GN_BWD_REG
+        return launch_status("groupnorm_bwd");
+    }
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
+                                         (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0,
+                                         (const T*)add0, (T*)dst1, (const T*)add1, dgamma, dbeta, sum_img, sum_ld, sum_all));
+    return launch_status("groupnorm_bwd");
+}
+
 extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                       const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                       void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta,
-                                      float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream);
+                                      float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream) {
+    MDM_REQUIRE(!(sum_img || sum_all) || acc0 == 0, "groupnorm_bwd_sums: column sums need a plain (non-accumulating) dx");
+    return mdm_groupnorm_bwd_add(dtype, src0, C0, src1, C1, N, P, G, gamma, beta, silu, dy, stats, dst0, acc0 ? dst0 : nullptr,
+                                 dst1, acc1 ? dst1 : nullptr, dgamma, dbeta, sum_img, sum_ld, sum_all, ws, stream);
+}
 
 extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                  const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
@@ -803,41 +824,6 @@ extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void
                                  void* stream) {
     return mdm_groupnorm_bwd_sums(dtype, src0, C0, src1, C1, N, P, G, gamma, beta, silu, dy, stats, dst0, acc0, dst1, acc1,
                                   dgamma, dbeta, nullptr, 0, nullptr, ws, stream);
-}
-
-extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
-                                      const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
-                                      void* dst0, int acc0, void* dst1, int acc1, float* dgamma, float* dbeta,
-                                      float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream) {
-    if (int rc = gn_check(C0, C1, G, N, P)) return rc;
-    const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
-    MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
-    MDM_REQUIRE(!(sum_img || sum_all) || (acc0 == 0 && C1 == 0), "groupnorm_bwd_sums: column sums need a plain (non-accumulating, single-source) dx");
-    dim3 grid(N, cdiv(C, cblk));
-    const int np = cdiv(P, 256 / (cblk / 8));
-    const int chunks = cdiv(np, 4);
-    if (dtype == MDM_BF16 && g_gn_regs && g_gn_split && ws && np > 4 && chunks <= 32 && (int64_t)grid.x * grid.y < 512) {
-        dim3 g3(grid.x, grid.y, chunks);
-#define GN_BWD_SPLIT(M) hipLaunchKernelGGL((gn_bwd_reg_kernel<4, M>), g3, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
-                                           (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
-                                           (bf16_t*)dst0, acc0, (bf16_t*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all, ws)
-        GN_BWD_SPLIT(1); GN_BWD_SPLIT(2);
-#undef GN_BWD_SPLIT
-        return launch_status("groupnorm_bwd");
-    }
-    if (dtype == MDM_BF16 && np <= 16 && g_gn_regs) {
-#define GN_BWD_REG(NPV) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
-                                           (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
-                                           (bf16_t*)dst0, acc0, (bf16_t*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all, ws)
-        if (np <= 1) GN_BWD_REG(1); else if (np <= 2) GN_BWD_REG(2); else if (np <= 4) GN_BWD_REG(4);
-        else if (np <= 8) GN_BWD_REG(8); else GN_BWD_REG(16);
-#undef GN_BWD_REG
-        return launch_status("groupnorm_bwd");
-    }
-    DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
-                                         (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0, acc0,
-                                         (T*)dst1, acc1, dgamma, dbeta, sum_img, sum_ld, sum_all));
-    return launch_status("groupnorm_bwd");
 }
 
 #ifdef MDM_STAMP
@@ -893,8 +879,13 @@ extern "C" int mdm_sumpool2(int dtype, const void* g, void* dst, int acc, int N,
 
 extern "C" int mdm_add(int dtype, void* dst, const void* src, int64_t n, void* stream) {
     MDM_REQUIRE(n % 8 == 0 && dst && src, "add: n must be a multiple of 8");
-    DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (T*)dst, (const T*)src, n / 8));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (T*)dst, (const T*)dst, (const T*)src, n / 8));
     return launch_status("add");
+}
+extern "C" int mdm_add3(int dtype, void* dst, const void* x, const void* y, int64_t n, void* stream) {
+    MDM_REQUIRE(n % 8 == 0 && dst && x, "add3: n must be a multiple of 8");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(stream_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (T*)dst, (const T*)x, (const T*)y, n / 8));
+    return launch_status("add3");
 }
 
 extern "C" int mdm_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int Cp, void* stream) {

@@ -30,9 +30,9 @@ class GemmDesc(C.Structure):
         ("src0", vp), ("src1", vp), ("ld0", i32), ("ld1", i32), ("wtap", i64),
         ("D0", vp), ("D1", vp), ("ldd0", i32), ("ldd1", i32), ("N0", i32), ("out_f32", i32), ("alpha", f32),
         ("acc0", i32), ("acc1", i32), ("bias", vp), ("rowvec", vp), ("rv_ld", i32), ("rows_per_img", i32),
-        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp), ("defer_reduce", i32), ("defer_launch", i32),
+        ("resid", vp), ("ldr", i32), ("splitk", i32), ("dtap", i64), ("ws", vp), ("ws_bytes", i64), ("dbias", vp),
         ("gnb_x", vp), ("gnb_stats", vp), ("gnb_gamma", vp), ("gnb_beta", vp), ("gnb_dgamma", vp), ("gnb_dbeta", vp),
-        ("gnb_sum_img", vp), ("gnb_sum_all", vp), ("gnb_G", i32), ("gnb_silu", i32), ("gnb_sum_ld", i32), ("_p3", i32),
+        ("gnb_sum_img", vp), ("gnb_sum_all", vp), ("gnb_G", i32), ("gnb_silu", i32), ("gnb_sum_ld", i32), ("_p3", i32), ("gnb_add", vp),
         ("gnf_out", vp), ("gnf_gamma", vp), ("gnf_beta", vp), ("gnf_stats", vp), ("gnf_G", i32), ("gnf_silu", i32), ("gnf_eps", f32), ("_p4", i32),
     ]
 
@@ -41,15 +41,17 @@ _PROTOS = {
     "mdm_version": ([], i32),
     "mdm_device_count": ([], i32),
     "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
-    "mdm_splitk_reduce_pending": ([vp], i32),
-    "mdm_gemm_flush": ([vp], i32),
-    "mdm_gemm_discard_pending": ([], i32),
+    "mdm_wgrad_group_accepts": ([C.POINTER(GemmDesc)], i32),
+    "mdm_wgrad_group_create": ([C.POINTER(GemmDesc), i32, vp, i64, C.POINTER(i64), C.POINTER(vp)], i32),
+    "mdm_wgrad_group_launch": ([vp, vp], i32),
+    "mdm_wgrad_group_destroy": ([vp], i32),
     "mdm_gemm_plan": ([C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i64)], i32),
     "mdm_gemm_can_fuse_gn_bwd": ([C.POINTER(GemmDesc), i32], i32),
     "mdm_gemm_can_fuse_gn_fwd": ([C.POINTER(GemmDesc), i32], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], i32),
+    "mdm_groupnorm_bwd_add": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
     "mdm_softmax_fwd": ([i32, vp, i32, i32, vp], i32),
     "mdm_softmax_bwd": ([i32, vp, vp, i32, i32, vp], i32),
     "mdm_timestep_embedding": ([vp, i32, i32, vp, vp], i32),
@@ -58,6 +60,7 @@ _PROTOS = {
     "mdm_colsum": ([i32, vp, i32, i32, i32, vp, i32, i32, vp, vp], i32),
     "mdm_sumpool2": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_add": ([i32, vp, vp, i64, vp], i32),
+    "mdm_add3": ([i32, vp, vp, vp, i64, vp], i32),
     "mdm_nchw_to_nhwc": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_nhwc_to_nchw": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_draw_timesteps": ([vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),
@@ -117,7 +120,6 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().mdm_last_error().decode()
-        load().mdm_gemm_discard_pending()           # a failed sequence must not leave queued launches / reductions behind
         raise RuntimeError(f"libmdm_hip {what} failed ({rc}): {msg}")
 
 
@@ -144,14 +146,10 @@ class Recording:
 
     def run(self, st=None):
         st = stream() if st is None else st
-        try:
-            for name, fn, args in self.calls:
-                rc = fn(*args, st)
-                if rc != 0:
-                    check(rc, name)
-        except BaseException:
-            load().mdm_gemm_discard_pending()       # an abandoned sequence must not leave queued launches behind
-            raise
+        for name, fn, args in self.calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                check(rc, name)
 
     def extend(self, other):
         base = len(self.calls)
@@ -240,12 +238,7 @@ class GraphExec:
         self.handle = handle
 
     def launch(self, st=None):
-        dbg = os.environ.get("MDM_DBG_SYNC") == "1"
-        if dbg:
-            torch.cuda.synchronize()
         check(load().mdm_graph_launch(self.handle, stream() if st is None else st), "mdm_graph_launch")
-        if dbg:
-            torch.cuda.synchronize()
 
     def __del__(self):
         try:
@@ -305,9 +298,45 @@ def gemm_plan(**kw):
     return sk.value, nb.value
 
 
-def reduce_call():
-    """A recorded-call entry for mdm_splitk_reduce_pending (appended to backward chunks cut out of a plan)."""
-    return ("mdm_splitk_reduce_pending", getattr(load(), "mdm_splitk_reduce_pending"), ())
+class WgradGroup:
+    """Handle of mdm_wgrad_group_*: a set of weight-gradient descriptors that run as ONE launch (+ one launch summing
+    their split-K partials).  `fields_list`: keyword dicts like `gemm()` takes.  The device table lives in a tensor
+    owned here; operands are referenced by pointer, so the caller keeps them alive."""
+
+    def __init__(self, fields_list, device):
+        lib = load()
+        n = len(fields_list)
+        self.flops = sum(f.pop("_flops", 0.0) for f in fields_list)
+        arr = (GemmDesc * n)()
+        for i, f in enumerate(fields_list):
+            d = _desc(f)
+            C.memmove(C.byref(arr, i * C.sizeof(GemmDesc)), C.byref(d), C.sizeof(GemmDesc))
+        need, h = i64(), vp()
+        check(lib.mdm_wgrad_group_create(arr, n, None, 0, C.byref(need), C.byref(h)), "mdm_wgrad_group_create")
+        self.table = torch.empty(need.value, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        check(lib.mdm_wgrad_group_create(arr, n, self.table.data_ptr(), need.value, C.byref(need), C.byref(h)), "mdm_wgrad_group_create")
+        assert h.value, "wgrad group was not built"
+        self.handle, self.n, self.keep = h, n, fields_list
+
+    def launch(self):
+        """Launch (or record) the group on the current stream."""
+        if _recording is not None:
+            _recording.keep.append(self)
+            _recording.flops[len(_recording.calls)] = (self.flops, BF16)
+        call("mdm_wgrad_group_launch", self.handle, stream())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().mdm_wgrad_group_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def wgrad_group_accepts(**kw):
+    kw.pop("_flops", None)
+    return bool(load().mdm_wgrad_group_accepts(C.byref(_desc(kw))))
 
 
 def gemm(**kw):

@@ -118,7 +118,8 @@ def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None
     if gnb is not None:
         f.update(gnb_x=gnb["x"], gnb_stats=gnb["stats"], gnb_gamma=gnb["gamma"], gnb_beta=gnb["beta"],
                  gnb_dgamma=gnb["dgamma"], gnb_dbeta=gnb["dbeta"], gnb_G=int(gnb.get("G", 32)), gnb_silu=int(bool(gnb["silu"])),
-                 gnb_sum_img=gnb.get("sum_img"), gnb_sum_ld=int(gnb.get("sum_ld", 0)), gnb_sum_all=gnb.get("sum_all"))
+                 gnb_sum_img=gnb.get("sum_img"), gnb_sum_ld=int(gnb.get("sum_ld", 0)), gnb_sum_all=gnb.get("sum_all"),
+                 gnb_add=gnb.get("add"))
     _lib.gemm(**f)
 
 
@@ -131,32 +132,33 @@ def conv_dgrad_t_can_fuse_gn_bwd(dt, g: ConvGeom, G=32):
     return bool(_lib.load().mdm_gemm_can_fuse_gn_bwd(_lib.C.byref(_lib._desc(f)), int(G)))
 
 
-def _wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer, defer_launch=False):
+def wgrad_fields(dt, g, dy, src0, src1, dw, splitk=0, ws=None, dbias=None, acc=1):
+    """Descriptor fields of a weight gradient (for `conv_wgrad`, or for a `_lib.WgradGroup`)."""
     return dict(dtype=dt, layout=2, M=g.Cout, N=g.Cin, K=g.N * g.OH * g.OW,
                 conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
                 pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
                 src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, A=dy, lda=g.Cout,
-                D0=dw, ldd0=g.Cin, N0=g.Cin, out_f32=1, acc0=1, splitk=splitk, dtap=g.Cout * g.Cin, _flops=conv_flops(g),
-                ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0), dbias=dbias, defer_reduce=int(bool(defer)),
-                defer_launch=int(bool(defer_launch)))
+                D0=dw, ldd0=g.Cin, N0=g.Cin, out_f32=1, acc0=int(acc), splitk=splitk, dtap=g.Cout * g.Cin, _flops=conv_flops(g),
+                ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0), dbias=dbias)
 
 
-def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None, dbias=None, defer=False, defer_launch=False):
-    """dw[tap][Cout][Cin] (fp32) += sum_pixels dy x gathered input.  `ws`: fp32 split-K workspace tensor;
-    `dbias` (bf16 path only): fp32 [Cout] that also receives += column sums of dy.  `defer`: leave the sum of
-    the split-K partials to the next splitk_reduce_pending() (ws must be this call's own slice).  `defer_launch`
-    (with defer): queue the contraction itself; it shares the launch of the next weight gradient."""
-    _lib.gemm(**_wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, defer, defer_launch))
+def conv_wgrad(dt, g: ConvGeom, dy, src0, src1, dw, splitk=0, ws=None, dbias=None, acc=1):
+    """dw[tap][Cout][Cin] (fp32) (+)= sum_pixels dy x gathered input.  `ws`: fp32 split-K workspace tensor;
+    `dbias` (bf16 path only): fp32 [Cout] that also receives += column sums of dy."""
+    _lib.gemm(**wgrad_fields(dt, g, dy, src0, src1, dw, splitk, ws, dbias, acc))
 
 
 def conv_wgrad_ws_bytes(dt, g: ConvGeom):
-    """Workspace bytes conv_wgrad wants for this geometry (0: no partial slabs)."""
-    f = _wgrad_fields(dt, g, 16, 16, 16 if g.C1 else None, 16, 0, None, None, False)    # dummy non-null pointers: no launch
+    """Workspace bytes conv_wgrad wants for this geometry under mdm_gemm's own split rule (0: no partial slabs)."""
+    f = wgrad_fields(dt, g, 16, 16, 16 if g.C1 else None, 16)    # dummy non-null pointers: no launch
     return _lib.gemm_plan(**f)[1]
 
 
-def splitk_reduce_pending():
-    call("mdm_splitk_reduce_pending", stream())
+def wgrad_group_split(g: ConvGeom, slabs_per_item=48):
+    """k-splits of a weight gradient that runs inside a group: the group fills the chip, so a layer is only cut
+    into work items of ~slabs_per_item 64-pixel slabs (never below 8) -- not into as many as fill 256 CUs alone."""
+    nslabs = (g.N * g.OH * g.OW) // 64
+    return max(1, min(int(round(nslabs / float(slabs_per_item))), nslabs // 8))
 
 
 def matmul(dt, layout, M, N, K, A, lda, B, ldb, D, ldd, batch=1, sA=0, sB=0, sD=0, alpha=1.0, bias=None,
@@ -172,9 +174,13 @@ def groupnorm_fwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, y, stats, ws,
 
 
 def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, dst0, acc0, dst1, acc1,
-                  dgamma, dbeta, ws, G=32, sum_img=None, sum_ld=0, sum_all=None):
-    call("mdm_groupnorm_bwd_sums", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
-         ptr(stats), ptr(dst0), int(acc0), ptr(dst1), int(acc1), ptr(dgamma), ptr(dbeta), ptr(sum_img), sum_ld,
+                  dgamma, dbeta, ws, G=32, sum_img=None, sum_ld=0, sum_all=None, add0=None, add1=None):
+    """dst = (acc ? dst : add or 0) + dx.  add0 / add1: tensors laid out like dst0 / dst1 that are added without being
+    modified (the gradient arriving over a residual branch)."""
+    a0 = dst0 if acc0 else add0
+    a1 = dst1 if acc1 else add1
+    call("mdm_groupnorm_bwd_add", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
+         ptr(stats), ptr(dst0), ptr(a0), ptr(dst1), ptr(a1), ptr(dgamma), ptr(dbeta), ptr(sum_img), sum_ld,
          ptr(sum_all), ptr(ws), stream())
 
 
@@ -216,6 +222,11 @@ def nhwc_to_nchw(dt, x, y, N, C, H, W, Cp):
 
 def add_(dt, dst, src):
     call("mdm_add", dt, ptr(dst), ptr(src), dst.numel(), stream())
+
+
+def add3(dt, dst, x, y=None):
+    """dst = x + y (y None: a copy)."""
+    call("mdm_add3", dt, ptr(dst), ptr(x), ptr(y), dst.numel(), stream())
 
 
 def fill(t, v):

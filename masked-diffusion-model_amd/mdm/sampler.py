@@ -15,7 +15,6 @@ What is different from the reference loop (same arithmetic, same RNG order in re
 from __future__ import annotations
 
 import numpy as np
-import os
 import torch
 
 from . import _lib, ops
@@ -222,8 +221,7 @@ class Sampler:
         hist = None
         if hist_mode:
             hist = {k: torch.zeros(T + 1, n, c, hw, hw, device=dev) for k in HISTORY_NAMES}
-        if (fused and not hist_mode and S.rng_mode == "device" and model.use_graph
-                and os.environ.get("MDM_SAMPLER_GRAPH", "1") != "0"):
+        if fused and not hist_mode and S.rng_mode == "device" and model.use_graph and getattr(a, "sampler_graph", True):
             return self._sample_graph(model, timesteps, x_t, dep, mode), []
         x0_hat = torch.empty_like(x_t)
         pred_nchw = torch.empty_like(x_t) if hist_mode else None

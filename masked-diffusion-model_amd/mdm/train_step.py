@@ -173,8 +173,7 @@ class TrainStep:
         chunks, lo = [], 0
         for hi in cuts:
             r = _lib.Recording()
-            r.calls = list(m.backward_plan.calls[lo:hi])
-            r.calls.append(_lib.reduce_call())      # the chunk's deferred split-K sums, before its bucket is exchanged
+            r.calls = list(m.backward_plan.calls[lo:hi])      # cuts sit right behind a grouped weight-gradient launch
             r.keep = m.backward_plan.keep
             chunks.append(r)
             lo = hi

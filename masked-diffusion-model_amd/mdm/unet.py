@@ -44,6 +44,7 @@ class Act:
         self.data = None
         self.grad = None
         self.grad_written = False
+        self.pending_add = None       # a gradient contribution (another activation's grad tensor) not yet folded into `grad`
         self.needs_grad = needs_grad
 
     @property
@@ -202,35 +203,38 @@ class _Conv:
 
     def bwd(self):
         n, st, g = self.net, self.net.store, self.g
-        assert self.out.grad_written, self.name
-        dy = self.out.grad
+        dy = n.grad_for_read(self.out)
         r = self.resid
-        if r is not None and r.needs_grad:       # y = conv(..) + resid  (unet6.py:333, 362)
-            if not r.grad_written:
-                r.grad, r.grad_written = dy, True      # alias: dy is dead after this op, later ops += into it
-            else:
-                ops.add_(n.dt, r.grad, dy)
         per, ld = (None, 0)
         if self.fc_slot is not None:
             per, ld = n.dT_all[:, self.fc_slot:], n.fc_total
         s0, s1 = self.src0, self.src1
-        # The parameter gradients (bias sums, weight gradient) and the data gradient only READ dy:
-        # they run as two parallel branches (side stream / main stream) and meet again before anything
-        # may overwrite dy (it can be aliased as the residual's gradient and accumulated into later).
-        fork = s0.needs_grad and (n.concurrent_bwd == 1 or (n.concurrent_bwd == 2 and g.OH * g.OW <= 64))
-        if fork:
-            _lib.call("mdm_fork", _lib.stream())
         fuse_bias = n.dt == BF16 and self.fc_slot is None     # bias sums ride along in the weight-gradient kernel
         if not fuse_bias and not getattr(self, "sums_by_norm", False):
             ops.colsum(n.dt, dy, g.N, g.OH * g.OW, g.Cout, per_img=per, ld=ld, acc_img=0, dbias=st.g(self.name + ".bias"))
-        # split-K partials go to this conv's own slice of the arena; ONE kernel sums all of them at the end of
-        # the backward (or of a gradient-bucket chunk): UNet._emit_bwd / TrainStep._build_graphs
-        own = getattr(self, "wgrad_ws", None)
-        ops.conv_wgrad(n.dt, g, dy, self.src0.data, self.src1.data if self.src1 else None, st.g(self.name + ".weight"),
-                       ws=own if own is not None else n.splitk_ws, dbias=st.g(self.name + ".bias") if fuse_bias else None,
-                       defer=own is not None, defer_launch=own is not None and getattr(self, "pair_wgrad", False))
-        if fork:
-            _lib.call("mdm_side_end", _lib.stream())
+        # Weight gradient.  It only READS dy and the layer input, and both stay in memory: on the bf16 path it is not
+        # launched here but collected into the current GROUP (UNet._flush_wgrads: one launch for a whole stretch of the
+        # backward, overwriting G -- no read of the zero-filled gradient).  dy must then stay untouched until the flush.
+        wf = ops.wgrad_fields(n.dt, g, dy, s0.data, s1.data if s1 else None, st.g(self.name + ".weight"),
+                              dbias=st.g(self.name + ".bias") if fuse_bias else None)
+        grouped = n.dt == BF16 and n.group_wgrads and _lib.wgrad_group_accepts(**wf)
+        if grouped:
+            wf["acc0"] = 0
+            wf["splitk"] = sk = ops.wgrad_group_split(g)
+            if sk > 1:
+                wf["ws"] = n.wgrad_slab(sk * g.taps * g.Cout * g.Cin)
+                wf["ws_bytes"] = wf["ws"].numel() * 4
+            n.pending_wgrads.append((self, wf))
+        else:
+            ops.conv_wgrad(n.dt, g, dy, s0.data, s1.data if s1 else None, st.g(self.name + ".weight"), ws=n.splitk_ws,
+                           dbias=st.g(self.name + ".bias") if fuse_bias else None)
+        if r is not None and r.needs_grad:       # y = conv(..) + resid  (unet6.py:333, 362): d(resid) += dy
+            if r.grad_written:
+                ops.add_(n.dt, r.grad, dy)
+            elif grouped:
+                r.pending_add = dy               # folded in by the next writer of r.grad (dst = dy + dx): dy stays intact
+            else:
+                r.grad, r.grad_written = dy, True      # alias: dy is dead after this op, later ops += into it
         if not s0.needs_grad:
             return
         # bf16: the filters come from the per-tap transposed shadow so both operands are k-contiguous
@@ -240,32 +244,31 @@ class _Conv:
         else:
             dgrad, wmat = ops.conv_dgrad, st.w(self.name + ".weight")
         nm = getattr(s0, "norm_spec", None)          # the GroupNorm that produced this conv's input (if any)
-        if (n.dt == BF16 and n.fuse_gn_bwd and nm is not None and nm.src1 is None and s1 is None and not g.ups and not fork
+        if (n.dt == BF16 and nm is not None and nm.src1 is None and s1 is None and not g.ups
                 and ops.conv_dgrad_t_can_fuse_gn_bwd(n.dt, g)):
             # 4x4 / 8x8 maps: the data gradient runs on whole-image tiles, so the GroupNorm backward is its epilogue --
             # d(z) never goes to memory and the GroupNorm launch disappears (_Norm.bwd sees bwd_fused)
             x = nm.src0
-            gx, ax = n.grad_for_write(x)
+            gx, ax, addx = n.grad_for_write(x, want_add=True)
             sums = {}
             prod = getattr(nm, "producer", None)     # conv1 of a ResidualBlock: this dx is its complete dY
-            if prod is not None and ax == 0:
+            if prod is not None and ax == 0 and addx is None:
                 sums = dict(sum_img=n.dT_all[:, prod.fc_slot:], sum_ld=n.fc_total, sum_all=st.g(prod.name + ".bias"))
                 prod.sums_by_norm = True
             ops.conv_dgrad_t(n.dt, g, dy, wmat, gx, ax, ws=n.splitk_ws,
                              gnb=dict(x=x.data, stats=nm.stats, gamma=st.f(nm.name + ".weight"), beta=st.f(nm.name + ".bias"),
-                                      dgamma=st.g(nm.name + ".weight"), dbeta=st.g(nm.name + ".bias"), G=32, silu=nm.silu, **sums))
+                                      dgamma=st.g(nm.name + ".weight"), dbeta=st.g(nm.name + ".bias"), G=32, silu=nm.silu,
+                                      add=addx, **sums))
             nm.bwd_fused = True
         elif g.ups:
             tmp = n.scratch(g.N * g.VH * g.VW * g.Cin)
             dgrad(n.dt, g, dy, wmat, tmp, 0)
-            g0, a0 = n.grad_for_write(s0)
+            g0, a0, _ = n.grad_for_write(s0)
             ops.sumpool2(n.dt, tmp, g0, a0, g.N, g.IH, g.IW, g.Cin)
         else:
-            g0, a0 = n.grad_for_write(s0)
-            g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
+            g0, a0, _ = n.grad_for_write(s0)
+            g1, a1, _ = n.grad_for_write(s1) if s1 is not None else (None, 0, None)
             dgrad(n.dt, g, dy, wmat, g0, a0, g1, a1)
-        if fork:
-            _lib.call("mdm_join", _lib.stream())
 
 
 class _Norm:
@@ -285,7 +288,7 @@ class _Norm:
         # (its recorded descriptor gets the gnf_* epilogue; no GroupNorm launch)
         k = n.specs.index(self)
         prev = n.specs[k - 1] if k > 0 else None
-        if (n.dt == BF16 and n.fuse_gn_fwd and _lib._recording is not None and s1 is None and isinstance(prev, _Conv)
+        if (n.dt == BF16 and _lib._recording is not None and s1 is None and isinstance(prev, _Conv)
                 and prev.out is s0 and getattr(prev, "fwd_desc", None) is not None and ops.conv_fwd_can_fuse_gn(prev.fwd_desc)):
             ops.fuse_gn_fwd(prev.fwd_desc, dict(out=self.out.data, gamma=st.f(self.name + ".weight"), beta=st.f(self.name + ".bias"),
                                                 stats=self.stats, G=32, silu=self.silu, eps=1e-6))
@@ -298,17 +301,18 @@ class _Norm:
         s0, s1 = self.src0, self.src1
         if getattr(self, "bwd_fused", False):       # done in the epilogue of the consuming conv's data gradient
             return
-        assert self.out.grad_written, self.name
-        g0, a0 = n.grad_for_write(s0)
-        g1, a1 = n.grad_for_write(s1) if s1 is not None else (None, 0)
+        dyo = n.grad_for_read(self.out)
+        g0, a0, add0 = n.grad_for_write(s0, want_add=True)
+        g1, a1, add1 = n.grad_for_write(s1, want_add=True) if s1 is not None else (None, 0, None)
         sums = {}
         prod = getattr(self, "producer", None)      # conv1 of a ResidualBlock: this dx is its complete dY
-        if prod is not None and a0 == 0 and s1 is None:
+        if prod is not None and a0 == 0 and add0 is None and s1 is None:
             sums = dict(sum_img=n.dT_all[:, prod.fc_slot:], sum_ld=n.fc_total, sum_all=st.g(prod.name + ".bias"))
             prod.sums_by_norm = True
         ops.groupnorm_bwd(n.dt, s0.data, s0.C, s1.data if s1 else None, s1.C if s1 else 0, s0.N, s0.P,
-                          st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, self.out.grad, self.stats,
-                          g0, a0, g1, a1, st.g(self.name + ".weight"), st.g(self.name + ".bias"), n.gn_ws, **sums)
+                          st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, dyo, self.stats,
+                          g0, a0, g1, a1, st.g(self.name + ".weight"), st.g(self.name + ".bias"), n.gn_ws,
+                          add0=add0, add1=add1, **sums)
 
 
 class _AttnCore:
@@ -333,12 +337,11 @@ class _AttnCore:
     def bwd(self):
         n, q, o = self.net, self.qkv, self.out
         N, L, C = q.N, q.P, o.C
-        assert o.grad_written
-        dqkv, acc = n.grad_for_write(q)
+        do = n.grad_for_read(o)
+        dqkv, acc, _ = n.grad_for_write(q)
         assert acc == 0
         d = q.data.view(N, L, 3 * C)
         g = dqkv.view(N, L, 3 * C)
-        do = o.grad
         sc = 1.0 / math.sqrt(C)
         dP = n.alloc((N, L, L), n.tdtype)
         s3, sl, sc_ = L * 3 * C, L * L, L * C
@@ -398,7 +401,7 @@ class UNet:
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
     def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True,
-                 _dry=False):
+                 group_wgrads=True, wgrad_group_bytes=24 << 20, _dry=False):
         if _dry:       # shape/parameter bookkeeping only (no device, no kernels): see `param_table`
             self.cfg, self.N, self.H, self.W, self.dt = dict(cfg), N, H, W, dtype
             self.store = ParamStore()
@@ -419,9 +422,10 @@ class UNet:
         self._scratch = None
         self._scratch_n = 0
         self.use_graph = use_graph
-        self.fuse_gn_bwd = os.environ.get("MDM_FUSE_GN_BWD", "1") != "0"
-        self.fuse_gn_fwd = os.environ.get("MDM_FUSE_GN_FWD", "1") != "0"
-        self.concurrent_bwd = int(os.environ.get("MDM_CONCURRENT_BWD", "0"))    # 1: every conv, 2: only maps <= 8x8    # measured slower (10.96 vs 10.57 ms/step at cfg2)
+        self.group_wgrads = group_wgrads            # weight gradients of the bf16 path run as grouped launches
+        self.wgrad_group_bytes = wgrad_group_bytes  # a group is flushed once it covers this many bytes of fp32 gradient
+        self.pending_wgrads = []
+        self.wgrad_groups = []
         shared = store is not None
         self.store = store if shared else ParamStore()
         self._build_specs()
@@ -606,12 +610,51 @@ class UNet:
             self._scratch_n = numel
         return self._scratch
 
-    def grad_for_write(self, act):
+    def grad_for_write(self, act, want_add=False):
+        """-> (grad tensor, acc, add): the caller writes grad = (acc ? grad : add or 0) + its contribution.  `add` is a
+        pending contribution (the untouched dy of a residual join, see _Conv.bwd); only callers that can add a second
+        tensor ask for it (want_add), for the others it is folded in by a separate launch first."""
         if act.grad is None:
             act.grad = self.alloc((act.N, act.H, act.W, act.C), self.tdtype)
+        add = None
+        if act.pending_add is not None:
+            pend, act.pending_add = act.pending_add, None
+            if want_add and not act.grad_written:
+                add = pend
+            else:
+                ops.add3(self.dt, act.grad, pend, act.grad if act.grad_written else None)
+                act.grad_written = True
         acc = 1 if act.grad_written else 0
         act.grad_written = True
-        return act.grad, acc
+        return act.grad, acc, add
+
+    def grad_for_read(self, act):
+        """The complete gradient of `act` (every consumer has contributed by now), pending contribution included."""
+        if act.pending_add is not None:
+            pend, act.pending_add = act.pending_add, None
+            if not act.grad_written:
+                act.grad, act.grad_written = pend, True      # sole contribution: alias it (read-only from here on)
+            else:
+                ops.add_(self.dt, act.grad, pend)
+        assert act.grad_written, act.name
+        return act.grad
+
+    def wgrad_slab(self, numel):
+        """A slice of the split-K arena for one grouped weight gradient (fp32 elements); sized on first use."""
+        off = (self._slab_off + 63) // 64 * 64
+        self._slab_off = off + numel
+        if self._slab_arena is None or self._slab_off > self._slab_arena.numel():
+            raise RuntimeError("wgrad slab arena too small")       # sized by _materialize from the same split rule
+        return self._slab_arena[off:off + numel]
+
+    def _flush_wgrads(self):
+        """Emit the pending weight gradients as ONE grouped launch (+ one launch summing their split-K slabs)."""
+        if not self.pending_wgrads:
+            return
+        grp = _lib.WgradGroup([wf for _, wf in self.pending_wgrads], self.device)
+        self.wgrad_groups.append(grp)
+        self.pending_wgrads = []
+        grp.launch()
 
     def _materialize(self):
         st = self.store
@@ -632,17 +675,17 @@ class UNet:
         wmax = max(s.g.taps * s.g.Cout * s.g.Cin for s in self.specs if isinstance(s, _Conv))
         self.splitk_ws = self.alloc((16 * wmax,), torch.float32)
         self.splitk_ws2 = self.splitk_ws
-        # weight gradients: every conv gets its own slice for its split-K partials (sized by the library's own
-        # split rule), so their sums can be deferred into one batched launch per backward chunk
-        need = [(s, ops.conv_wgrad_ws_bytes(self.dt, s.g)) for s in self.specs if isinstance(s, _Conv)]
-        total = sum((nb + 255) // 256 * 256 for _, nb in need)
-        if total and os.environ.get("MDM_DEFER_REDUCE", "1") != "0":
-            arena = self.alloc((total // 4,), torch.float32)
-            off = 0
-            for s, nb in need:
-                if nb:
-                    s.wgrad_ws = arena[off // 4:(off + nb) // 4]
-                    off += (nb + 255) // 256 * 256
+        # grouped weight gradients: every split layer gets its own slice of one arena for its fp32 partial slabs
+        self._slab_arena, self._slab_off = None, 0
+        if self.dt == BF16 and self.group_wgrads:
+            need = 0
+            for sp in self.specs:
+                if isinstance(sp, _Conv):
+                    sk = ops.wgrad_group_split(sp.g)
+                    if sk > 1:
+                        need += (sk * sp.g.taps * sp.g.Cout * sp.g.Cin + 63) // 64 * 64 + 64
+            if need:
+                self._slab_arena = self.alloc((need,), torch.float32)
         self.x_nchw = self.alloc((self.N, self.cin, self.H, self.W), torch.float32)
         self.y_nchw = self.alloc((self.N, self.cout, self.H, self.W), torch.float32)
 
@@ -659,21 +702,25 @@ class UNet:
         """Backward of everything after `y_out.grad` has been written by the caller's loss kernel."""
         self.y_out.grad = self.alloc((self.N, self.H, self.W, self.cout_p), self.tdtype)
         self.y_out.grad_written = True
-        # bwd_marks[i] = (#launches emitted so far, lowest flat-buffer offset whose gradient is final):
-        # parameters are declared in forward order, so after the backward of spec j every gradient
-        # at or above spec j's first parameter is complete (mdm.dist.GradComm cuts buckets there).
+        # bwd_marks[i] = (#launches emitted so far, lowest flat-buffer offset whose gradient is final): parameters are
+        # declared in forward order, so once the backward of spec j AND the group holding its weight gradient have run,
+        # every gradient at or above spec j's first parameter is complete (mdm.dist.GradComm cuts buckets there).
+        # Weight gradients are collected and flushed as a group whenever they cover ~wgrad_group_bytes of gradient;
+        # marks exist only at those flush points.
         self.bwd_marks = []
-        # conv2 of a residual block queues its weight gradient; conv1's (two backward steps later, only norm2's
-        # backward in between, which touches neither operand) launches both in one kernel
-        if os.environ.get("MDM_PAIR_WGRAD", "1") != "0":
-            for i in range(2, len(self.specs)):
-                c2, nm, c1 = self.specs[i], self.specs[i - 1], self.specs[i - 2]
-                if isinstance(c2, _Conv) and isinstance(nm, _Norm) and getattr(nm, "producer", None) is c1 and c2.src0 is nm.out:
-                    c2.pair_wgrad = True
+        covered = 0
         for s in reversed(self.specs):
             s.bwd()
-            self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
-        ops.splitk_reduce_pending()         # the deferred split-K sums of every weight gradient above: one launch
+            if isinstance(s, _Conv):
+                covered += 4 * s.g.taps * s.g.Cout * s.g.Cin
+            if covered >= self.wgrad_group_bytes or s is self.specs[1]:
+                self._flush_wgrads()
+                covered = 0
+                self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
+        self._flush_wgrads()
+        self.bwd_marks.append((len(_lib._recording.calls), 0))
+        for a in self.acts:
+            assert a.pending_add is None, a.name
 
     def census(self):
         """Leaf-op output elements of ONE forward under the counting rule of SURVEY 8(d) (every

@@ -27,7 +27,8 @@ init_from_env("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=50, shift_type="noise_with_perturbation",
               rng_mode="device", use_ema=True, seed=100 + rank, use_graph=(sys.argv[2] == "graph"))
-model = mdm.UNet(TINY, N=4, H=16, W=16, dtype=mdm.BF16, params=random_params(TINY), use_graph=a.use_graph)
+model = mdm.UNet(TINY, N=4, H=16, W=16, dtype=mdm.BF16, params=random_params(TINY), use_graph=a.use_graph,
+                 wgrad_group_bytes=200 << 10)     # small weight-gradient groups: the tiny model still cuts into several buckets
 opt = mdm.AdamW(model, lr=1e-3)
 ema = mdm.EMA(model)
 S = mdm.Scheduler(a); S.update_ddpm_num_steps(50)

@@ -381,39 +381,57 @@ def test_softmax_colsum_pool_layout_temb(dt):
         assert (y.cpu() - timestep_embedding(t, 128)).abs().max() < 2e-4   # sin/cos of arguments up to 1e3
 
 
-def test_deferred_weight_gradients_match_immediate_ones():
-    """defer_reduce / defer_launch (mdm_hip.h): queued split-K sums (more than one table of 96 segments) and paired
-    launches give the same gradients as self-contained calls; mdm_gemm_plan sizes the workspace slices."""
-    from mdm import ops
+def test_grouped_weight_gradients_match_self_contained_ones():
+    """mdm_wgrad_group_* (mdm_hip.h): many weight gradients of mixed shapes (big / small tiles, split and unsplit,
+    concat, stride 2, folded upsample, more than one table of 96 split-K segments) as ONE grouped launch give the same
+    gradients and bias gradients as one mdm_gemm call each; overwrite and accumulate forms."""
+    from mdm import _lib, ops
     dt = "bf16"
     g = torch.Generator().manual_seed(77)
-    shapes = [(8, 8, 64, 64), (8, 8, 64, 128), (4, 16, 64, 64)]          # N, H, C, Cout
+    shapes = [(8, 8, 64, 0, 64, 1, 0), (8, 8, 64, 0, 128, 1, 0), (4, 16, 64, 64, 64, 1, 0), (4, 32, 128, 0, 128, 1, 0),
+              (8, 16, 64, 0, 64, 2, 0), (4, 8, 64, 0, 64, 1, 1), (16, 4, 256, 0, 256, 1, 0)]      # N, H, C0, C1, Cout, stride, ups
     jobs = []
-    for rep in range(34):                                                 # 102 deferred contractions > 96 per table
-        N, H, C, Cout = shapes[rep % 3]
-        geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
-        x = _up(_nhwc(_q(torch.randn(N, C, H, H, generator=g), dt)), dt)
-        gy = _up(_nhwc(_q(torch.randn(N, Cout, H, H, generator=g), dt)), dt)
+    for rep in range(231):
+        N, H, C0, C1, Cout, stride, ups = shapes[rep % len(shapes)]
+        pads = (1, 1, 1, 1) if stride == 1 else (0, 0, 1, 1)
+        geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, stride=stride, pad_t=pads[0], pad_l=pads[1], pad_b=pads[2],
+                            pad_r=pads[3], ups=ups)
+        x0 = _up(_nhwc(_q(torch.randn(N, C0, H, H, generator=g), dt)), dt)
+        x1 = _up(_nhwc(_q(torch.randn(N, C1, H, H, generator=g), dt)), dt) if C1 else None
+        gy = _up(_nhwc(_q(torch.randn(N, Cout, geom.OH, geom.OW, generator=g), dt)), dt)
+        jobs.append((geom, x0, x1, gy, rep % 3 == 0))
+    want = []
+    for geom, x0, x1, gy, acc in jobs:
         nb = ops.conv_wgrad_ws_bytes(1, geom)
-        assert nb > 0
-        jobs.append((geom, x, gy, nb))
-    want, got = [], []
-    for geom, x, gy, nb in jobs:
-        ws = torch.empty(nb // 4, device=_dev())
-        gw = torch.full((9, geom.Cout, geom.C0), 0.5, device=_dev())
-        ops.conv_wgrad(1, geom, gy, x, None, gw, ws=ws)                   # self-contained: own reduce launch
-        want.append(gw)
-    keep = []
-    for i, (geom, x, gy, nb) in enumerate(jobs):
-        ws = torch.full((nb // 4,), float("nan"), device=_dev())
-        gw = torch.full((9, geom.Cout, geom.C0), 0.5, device=_dev())
-        ops.conv_wgrad(1, geom, gy, x, None, gw, ws=ws, defer=True, defer_launch=(i % 2 == 0))
-        keep.append(ws); got.append(gw)
-    ops.splitk_reduce_pending()
+        ws = torch.empty(max(nb // 4, 16), device=_dev())
+        gw = torch.full((9, geom.Cout, geom.Cin), 0.5, device=_dev())
+        gb = torch.zeros(geom.Cout, device=_dev())
+        ops.conv_wgrad(1, geom, gy, x0, x1, gw, ws=ws, dbias=gb, acc=1)              # self-contained: own reduce launch
+        want.append((gw, gb))
+    fields, got, keep = [], [], []
+    n_split = 0
+    for geom, x0, x1, gy, acc in jobs:
+        gw = torch.full((9, geom.Cout, geom.Cin), 0.5, device=_dev())
+        gb = torch.zeros(geom.Cout, device=_dev())
+        wf = ops.wgrad_fields(1, geom, gy, x0, x1, gw, dbias=gb, acc=int(acc))
+        assert _lib.wgrad_group_accepts(**wf)
+        sk = max(ops.wgrad_group_split(geom, slabs_per_item=4), 1)                     # short items: most layers split
+        wf["splitk"] = sk
+        if sk > 1:
+            n_split += 1
+            ws = torch.full((sk * 9 * geom.Cout * geom.Cin,), float("nan"), device=_dev())
+            wf["ws"], wf["ws_bytes"] = ws, ws.numel() * 4
+            keep.append(ws)
+        fields.append(wf); got.append((gw, gb, acc))
+    assert n_split > 96
+    grp = _lib.WgradGroup(fields, _dev())
+    grp.launch()
     torch.cuda.synchronize()
-    for a, b in zip(got, want):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
-        assert float((b - 0.5).abs().max()) > 0.1                         # accumulated onto the initial value, and non-trivial
+    for (a, ab, acc), (b, bb) in zip(got, want):
+        ref = b if acc else b - 0.5                                                   # overwrite form: no initial value
+        assert float((a - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 2e-6
+        assert float((ab - bb).abs().max()) <= 1e-5 * float(bb.abs().max()) + 1e-5
+        assert float((b - 0.5).abs().max()) > 0.1                                     # non-trivial gradients
 
 
 @pytest.mark.parametrize("case", [(8, 8, 256, 256, True, False), (16, 4, 128, 256, True, True), (4, 8, 128, 64, False, False),

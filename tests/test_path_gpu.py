@@ -252,12 +252,11 @@ def test_sampler_one_graph_per_step_equals_the_host_driven_loop(dep, mode, sel, 
     import mdm
     from oracle.unet_ref import random_params
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("MDM_SAMPLER_GRAPH", flag)
+    for flag in (False, True):
         model = mdm.UNet(TINY, N=4, H=16, W=16, dtype=1, params=random_params(TINY)).eval()
         a = base_args(data_size=16, ddpm_schedule=sched, ddpm_num_steps=8, select_degrade_pixel=sel, degrade_channel="1-channel",
                       shift_type="noise_with_perturbation", sampling_mask_dependency=dep, momentum_adaptive=mode, sample_num=4,
-                      sample_latent_shape="uniform", sample_history=False, rng_mode="device", seed=5)
+                      sample_latent_shape="uniform", sample_history=False, rng_mode="device", seed=5, sampler_graph=flag)
         s = mdm.Scheduler(a)
         s.update_ddpm_num_steps(8)
         smp = mdm.Sampler(None, a, s, [None] * 3)
