@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--sampler-steps", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--wgrad-group-mb", type=float, default=None, help=argparse.SUPPRESS)      # experiments only
+    ap.add_argument("--overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
     opt_ = ap.parse_args()
@@ -220,10 +222,13 @@ def main():
     dev = torch.device("cuda", local)
     dt = mdm.BF16 if opt_.dtype == "bf16" else mdm.F32
     N = opt_.batch
-    args = make_args(batch_size=N, seed=1234 + rank, use_graph=not opt_.no_graph)   # per-rank RNG streams
+    args = make_args(batch_size=N, seed=1234 + rank, use_graph=not opt_.no_graph, overlap_wgrads=opt_.overlap)   # per-rank RNG streams
 
     cfg = mdm.unet6_config(32)
-    model = mdm.UNet(cfg, N=N, H=32, W=32, dtype=dt, seed=0, use_graph=not opt_.no_graph)   # same weights on every rank
+    xk = {}
+    if opt_.wgrad_group_mb is not None:
+        xk["wgrad_group_bytes"] = int(opt_.wgrad_group_mb * (1 << 20))
+    model = mdm.UNet(cfg, N=N, H=32, W=32, dtype=dt, seed=0, use_graph=not opt_.no_graph, **xk)   # same weights on every rank
     optim = mdm.AdamW(model, lr=1e-4)
     ema = mdm.EMA(model, decay=args.ema_max_decay, inv_gamma=args.ema_inv_gamma, power=args.ema_power)
     sched = mdm.Scheduler(args, device=dev)

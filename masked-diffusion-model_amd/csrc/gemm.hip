@@ -1815,11 +1815,15 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d, int
 // many k-splits as balance asks for (fewer fp32 partial slabs: the per-layer launches wrote and re-read ~0.9 GB
 // of them per step at cfg2), and ~70 launch gaps / prologues / drain tails per step disappear.
 // items[i] = {descriptor index, item index inside it, tiles per (tap, k-range), 1 = 128x128 tile / 0 = 64x64}.
-__global__ __launch_bounds__(512) void wgrad_group_kernel(const mdm_gemm_desc* descs, const int4* items) {
-    const int4 it = items[blockIdx.x];
-    const mdm_gemm_desc d = descs[it.x];
-    if (it.w) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
-    else wgrad_lin_body<64, 64, 4, 8>(d, it.y, it.z);
+__global__ __launch_bounds__(512) void wgrad_group_kernel(const mdm_gemm_desc* descs, const int4* items, int n_items) {
+    // grid == n_items: one item per workgroup; a smaller grid walks the (longest-first) list with stride gridDim.x
+    for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
+        const int4 it = items[i];
+        const mdm_gemm_desc d = descs[it.x];
+        if (it.w) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
+        else wgrad_lin_body<64, 64, 4, 8>(d, it.y, it.z);
+        __syncthreads();            // the next item refills the LDS ring
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -2332,7 +2336,7 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
 struct WgradGroup {
     const mdm_gemm_desc* descs_dev = nullptr;
     const int4* items_dev = nullptr;
-    int n_items = 0;
+    int n_items = 0, max_blocks = 0;
     std::vector<ReduceTable> reduces;       // the split-K sums of the group's split layers: passed by value at launch
     std::vector<int> reduce_blocks;
 };
@@ -2444,7 +2448,8 @@ extern "C" int mdm_wgrad_group_launch(void* handle, void* stream) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)g->n_items), dim3(512), bytes, s, g->descs_dev, g->items_dev);
+    const int nb = (g->max_blocks > 0 && g->max_blocks < g->n_items) ? g->max_blocks : g->n_items;
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)nb), dim3(512), bytes, s, g->descs_dev, g->items_dev, g->n_items);
     for (size_t i = 0; i < g->reduces.size(); ++i)
         hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)g->reduce_blocks[i]), dim3(256), 0, s, g->reduces[i]);
     return launch_status("wgrad group");

@@ -45,6 +45,8 @@ class TrainStep:
         self._used_key = None
         self._graphs = None
         self.use_graph = getattr(args, "use_graph", True)
+        self.overlap = bool(getattr(args, "overlap_wgrads", False))      # grouped weight gradients on a second stream
+        self.side = None
 
     # ---- pieces shared by both modes -------------------------------------------------------
     def _kind(self):
@@ -165,30 +167,55 @@ class TrainStep:
         ops.fill(m.store.G, 0.0)
 
     def _build_graphs(self):
+        """front = draws + degrade + shift + forward + loss; the backward is cut at every grouped weight-gradient launch
+        into [chain graph, group] pieces; tail = optimizer.  With `overlap` the groups are not part of any graph: each is
+        issued on a second stream as soon as the chain piece that produced its operands has been enqueued, so it runs
+        NEXT TO the following chain piece (hipGraph branches were measured NOT to run concurrently on this stack; two
+        streams do).  Data parallel: the bucket of a piece is all-reduced once its group has finished."""
         m = self.model
         with _lib.Recording() as front:
             self._emit_device_front()
-        # backward is cut into chunks at the gradient-bucket boundaries of the communicator
-        cuts = self.comm.plan_chunks(m) if self.comm is not None else [len(m.backward_plan.calls)]
-        chunks, lo = [], 0
-        for hi in cuts:
-            r = _lib.Recording()
-            r.calls = list(m.backward_plan.calls[lo:hi])      # cuts sit right behind a grouped weight-gradient launch
-            r.keep = m.backward_plan.keep
-            chunks.append(r)
-            lo = hi
+        calls = m.backward_plan.calls
+        is_group = lambda c: c[0] == "mdm_wgrad_group_launch"
+        # pieces: (chain calls, group call or None); bucket_after[j] = index of the bucket that is complete after piece j
+        pieces, lo = [], 0
+        for i, c in enumerate(calls):
+            if is_group(c):
+                pieces.append((calls[lo:i], c))
+                lo = i + 1
+        pieces.append((calls[lo:], None))
+        ends, pos = [], 0                       # number of calls consumed after each piece (group call included)
+        for chain, grp in pieces:
+            pos += len(chain) + (1 if grp is not None else 0)
+            ends.append(pos)
+        cuts = self.comm.plan_chunks(m) if self.comm is not None else []
+        self.bucket_after = {}
+        for b, c in enumerate(cuts):            # a bucket is complete after the first piece that ends at or behind its cut
+            j = next(k for k, e in enumerate(ends) if e >= c)
+            self.bucket_after.setdefault(j, []).append(b)
         with _lib.Recording() as tail:
             gmul = 1.0 / self.comm.world if self.comm is not None else 1.0
             self.opt.emit_update(self.ema.shadow if self.ema is not None else None, self.max_norm, gmul)
         mk = (lambda r: _lib.GraphExec(r)) if self.use_graph else (lambda r: r)
-        if self.comm is None:
-            # single GPU: nothing happens between the pieces, so the whole step is ONE graph
+
+        def rec(cs):
+            r = _lib.Recording()
+            r.calls, r.keep = list(cs), m.backward_plan.keep
+            return r
+        if self.comm is None and not self.overlap:
+            # single GPU, serial: nothing happens between the pieces, so the whole step is ONE graph
             whole = _lib.Recording()
-            for r in (front, chunks[0], tail):
-                whole.extend(r)
+            whole.extend(front); whole.extend(m.backward_plan); whole.extend(tail)
             self._graphs = (mk(whole), [], None)
+            return
+        if not self.overlap:                    # groups stay inside the chain graphs
+            built = [(mk(rec(list(chain) + ([grp] if grp is not None else []))), None) for chain, grp in pieces]
         else:
-            self._graphs = (mk(front), [mk(c) for c in chunks], mk(tail))
+            built = [(mk(rec(chain)) if chain else None, grp) for chain, grp in pieces]
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+                self.ev_main, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
+        self._graphs = (mk(front), built, mk(tail))
 
     def run_device(self, x0, used):
         """Device-RNG step as hipGraph replays.  `x0` None = reuse the batch already in `self.x0`."""
@@ -197,16 +224,32 @@ class TrainStep:
         self._upload_used(used)
         if self._graphs is None:
             self._build_graphs()
-        front, chunks, tail = self._graphs
+        front, pieces, tail = self._graphs
         self._hyper()
         go = (lambda g: g.launch()) if self.use_graph else (lambda g: g.run())
         go(front)
-        for i, c in enumerate(chunks):
-            go(c)
-            if self.comm is not None:
-                self.comm.reduce_bucket(i, self.model.store.G)
+        if tail is None:
+            return self.loss
+        main = torch.cuda.current_stream()
+        forked = False
+        for j, (chain, grp) in enumerate(pieces):
+            if chain is not None:
+                go(chain)
+            if grp is not None:                 # overlap: the group goes to the second stream, behind this chain piece
+                self.ev_main.record(main)
+                self.side.wait_event(self.ev_main)
+                _lib.check(grp[1](*grp[2], self.side.cuda_stream), grp[0])
+                forked = True
+            for b in (self.bucket_after.get(j, ()) if self.comm is not None else ()):
+                if grp is not None:
+                    with torch.cuda.stream(self.side):      # the exchange waits for the group, not for the chain
+                        self.comm.reduce_bucket(b, self.model.store.G)
+                else:
+                    self.comm.reduce_bucket(b, self.model.store.G)
+        if forked:
+            self.ev_side.record(self.side)
+            main.wait_event(self.ev_side)
         if self.comm is not None:
             self.comm.wait_all()
-        if tail is not None:
-            go(tail)
+        go(tail)
         return self.loss

@@ -401,7 +401,7 @@ class UNet:
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
     def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True,
-                 group_wgrads=True, wgrad_group_bytes=24 << 20, _dry=False):
+                 group_wgrads=True, wgrad_group_bytes=32 << 20, _dry=False):
         if _dry:       # shape/parameter bookkeeping only (no device, no kernels): see `param_table`
             self.cfg, self.N, self.H, self.W, self.dt = dict(cfg), N, H, W, dtype
             self.store = ParamStore()
@@ -648,13 +648,16 @@ class UNet:
         return self._slab_arena[off:off + numel]
 
     def _flush_wgrads(self):
-        """Emit the pending weight gradients as ONE grouped launch (+ one launch summing their split-K slabs)."""
+        """Emit the pending weight gradients as ONE grouped launch (+ one launch summing their split-K slabs).
+        (TrainStep lifts these calls out of the captured chain and issues them on a second stream, next to the
+        data-gradient chain that follows.)  -> True if something was launched."""
         if not self.pending_wgrads:
-            return
+            return False
         grp = _lib.WgradGroup([wf for _, wf in self.pending_wgrads], self.device)
         self.wgrad_groups.append(grp)
         self.pending_wgrads = []
         grp.launch()
+        return True
 
     def _materialize(self):
         st = self.store
@@ -715,9 +718,9 @@ class UNet:
                 covered += 4 * s.g.taps * s.g.Cout * s.g.Cin
             if covered >= self.wgrad_group_bytes or s is self.specs[1]:
                 self._flush_wgrads()
-                covered = 0
                 self.bwd_marks.append((len(_lib._recording.calls), s.param_lo))
-        self._flush_wgrads()
+                covered = 0
+        assert not self.pending_wgrads
         self.bwd_marks.append((len(_lib._recording.calls), 0))
         for a in self.acts:
             assert a.pending_add is None, a.name

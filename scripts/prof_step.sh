@@ -5,4 +5,4 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/run -- python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-sampler > $OUT/bench.log 2>&1
 cd $R
 cp $(ls -t $OUT/run/*/*kernel_stats.csv | head -1) $OUT/stats.csv
-python3 scripts/prof_summary.py $OUT/stats.csv 16
+python3 scripts/prof_summary.py $OUT/stats.csv
