@@ -6,9 +6,9 @@
 //               global loads so the gather can zero-fill and the rows can be padded
 //               against bank conflicts); k-strided operands are kept in their natural
 //               [k][col] image and read with ds_read_b64_tr_b16 (hardware transpose).
-//   fp32 path : exact-fp32 VALU contraction (64x64x16 tile, 4x4 per thread) used by
-//               the parity tests and the 1e-3 sampler check; shares every index
-//               function with the bf16 path.
+//   fp32 path : exact-fp32 contraction on v_mfma_f32_16x16x4_f32 (no reduced-precision step),
+//               the path of the parity tests and of the reverse sampler that meets 1e-3;
+//               shares every index function with the bf16 path.
 //
 // Replaces F.conv2d fwd/dgrad/wgrad, F.linear and the attention einsums
 // (reference unet6.py:170-171, 232-235, 316-324).
@@ -293,92 +293,185 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(mdm_gemm_desc d) {
 }
 
 // ----------------------------------------------------------------------------
-// fp32 VALU path
+// fp32 MFMA path: the same contraction on v_mfma_f32_16x16x4_f32 -- fp32 operands, fp32 accumulate, bit-for-bit a
+// k-ordered fmaf chain (no reduced-precision step anywhere), at the matrix pipe's fp32 rate (= the VALU peak, but
+// with one VGPR per operand per lane and the VALU free; MI355X_MICROARCH.md: 4096^3 at 122 TF against 52 TF on
+// v_pk_fma_f32).  This is the path whose reverse sampler meets north_star's 1e-3 (bf16 storage does not: measured
+// 1e-2 after 20 steps, 0.5 after 250), so it must not be slower than it has to be.
+//   256 threads = 4 waves as 2 x 2, tile BM x BN x 32, register-staged double-buffered LDS images [row][32 + 4]
+//   (k-strided operands are transposed on the way into LDS), fragments by ds_read_b128: a lane's 4 consecutive k
+//   feed 4 MFMAs (lane group g supplies k = 4 g + j to MFMA j -- the same permutation on both operands).
+// Shares every index function (gather, split-K ranges, epilogue) with the bf16 kernels.  (It replaced a 64x64x16
+// VALU kernel -- 4x4 fmaf per thread -- that ran the 1000-step fp32 sampler in 28.2 s; this one takes 17.5 s.)
 // ----------------------------------------------------------------------------
-template <int LAYOUT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(mdm_gemm_desc d) {
-    // BK: granule of the split-K chunks (host rule); KS: k per loop trip = 4 granules, so that four 16-byte
-    // loads per operand are in flight per thread, and the next trip's loads are issued before this trip's
-    // FMAs (the first version did load -> barrier -> store -> barrier -> FMA per 16 k: one full memory
-    // latency per granule, 28 us for the [32,512]x[4992,512] time-embedding projection).
-    constexpr int BM = 64, BN = 64, BK = 16, KS = 64, NQ = KS / BK, LD = 68;
-    __shared__ __attribute__((aligned(16))) float As[KS * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[KS * LD];
-    const int t = threadIdx.x;
+template <int BM, int BN, int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
+    constexpr int BK = 32, LD = BK + 4;
+    constexpr bool A_ROWS = (LAYOUT != 2), B_ROWS = (LAYOUT == 0);
+    constexpr int A_EL = BM * LD, B_EL = BN * LD, STAGE = A_EL + B_EL;
+    constexpr int NVA = BM * BK / 4 / 256, NVB = BN * BK / 4 / 256;        // float4 per thread per slab
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];              // [2][STAGE]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (d.N + BN - 1) / BN;
     const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-    const ZInfo z = decode_z(d, BK);
+    const ZInfo z = decode_z(d, 16);
+    // row-operand mapping: 8 float4 per 32-wide row, 32 rows per pass
+    const int rr = t >> 3, rk = (t & 7) * 4;
+    // col-operand mapping ([k][cols] in memory): AVR float4 per k-row
+    constexpr int AVR = BM / 4, BVR = BN / 4, AKP = 256 / AVR, BKP = 256 / BVR;
+    const int ack = t / AVR, acc_ = (t % AVR) * 4;
+    const int bck = t / BVR, bcc = (t % BVR) * 4;
 
-    const int rr = t >> 2, rk = (t & 3) * 4;     // row-operand mapping: 64 rows x 4 vectors (per granule)
-    const int ck = t >> 4, cc = (t & 15) * 4;    // col-operand mapping: 16 k-rows x 16 vectors (per granule)
-    RowPix arow = {0, 0, 0};
-    if (LAYOUT != 2 && d.conv && m0 + rr < d.M) arow = decode_row(d, m0 + rr);
-
-    float acc[4][4] = {};
-    const int ty = t >> 4, tx = t & 15;
-    float4 av[NQ], bv[NQ];
-    auto fetch = [&](int k0) {
+    RowPix arow[NVA];
+    if (A_ROWS && d.conv) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            av[q] = make_float4(0, 0, 0, 0); bv[q] = make_float4(0, 0, 0, 0);
-            const int kq = k0 + q * BK;
-            if (LAYOUT != 2) {
-                const float* p = a_row_ptr<float>(d, z, m0 + rr, arow, kq + rk);
-                if (p) av[q] = load4(p);
-            } else {
-                const float* p = a_col_ptr<float>(d, z, kq + ck, m0 + cc);
-                if (p) av[q] = load4(p);
+        for (int i = 0; i < NVA; ++i) {
+            const int gm = m0 + rr + 32 * i;
+            arow[i] = decode_row(d, gm < d.M ? gm : 0);
+        }
+    }
+    const int wg_ty = (LAYOUT == 2 && d.conv) ? z.tap / d.KW : 0;
+    const int wg_tx = (LAYOUT == 2 && d.conv) ? z.tap - wg_ty * d.KW : 0;
+    // tap-major fast path (layouts 0/1, gathered A, unsplit): every 32-slab lies inside one filter tap, so the source pixel
+    // of each of this thread's rows is computed once per tap and the slab loop has no integer division
+    const bool tapmajor = A_ROWS && d.conv && (d.Ck % BK == 0) && d.splitk <= 1;
+    int apix[NVA];
+    int cur_tap = -1, nxt_tap = 0, nxt_c = 0;
+    float4 ra[NVA], rb[NVB];
+    auto ld4 = [](const float* p) { return p ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f); };
+    auto load_tiles = [&](int k0) {
+        if (tapmajor) {
+            const bool live = nxt_tap < d.KH * d.KW;
+            if (live && nxt_tap != cur_tap) {
+                const int ty = nxt_tap / d.KW, tx = nxt_tap - ty * d.KW;
+#pragma unroll
+                for (int i = 0; i < NVA; ++i) apix[i] = (m0 + rr + 32 * i < d.M) ? gather_pix(d, arow[i], ty, tx) : -1;
+                cur_tap = nxt_tap;
             }
-            if (LAYOUT == 0) {
-                const float* p = b_row_ptr<float>(d, z, n0 + rr, kq + rk);
-                if (p) bv[q] = load4(p);
+            const int cc = nxt_c + rk;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) ra[i] = ld4(live ? pix_chan_ptr<float>(d, apix[i], cc) : nullptr);
+            const float* Bt = reinterpret_cast<const float*>(d.B) + (int64_t)nxt_tap * d.wtap;
+            if (B_ROWS) {
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) {
+                    const int gn = n0 + rr + 32 * i;
+                    rb[i] = ld4((live && gn < d.N) ? Bt + (int64_t)gn * d.ldb + cc : nullptr);
+                }
             } else {
-                const float* p = b_col_ptr<float>(d, z, kq + ck, n0 + cc);
-                if (p) bv[q] = load4(p);
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) {
+                    const int gn = n0 + bcc;
+                    rb[i] = ld4((live && gn < d.N) ? Bt + (int64_t)(nxt_c + bck + BKP * i) * d.ldb + gn : nullptr);
+                }
+            }
+            nxt_c += BK;
+            if (nxt_c >= d.Ck) { nxt_c = 0; ++nxt_tap; }
+            return;
+        }
+        if (A_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) ra[i] = ld4(a_row_ptr<float>(d, z, m0 + rr + 32 * i, arow[i], k0 + rk));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) ra[i] = ld4(a_col_ptr<float>(d, z, k0 + ack + AKP * i, m0 + acc_));
+        }
+        if (B_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) rb[i] = ld4(b_row_ptr<float>(d, z, n0 + rr + 32 * i, k0 + rk));
+        } else if (LAYOUT == 2 && d.conv) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = k0 + bck + BKP * i, gn = n0 + bcc;
+                const float* p = nullptr;
+                if (k < z.kend && gn < d.N) p = pix_chan_ptr<float>(d, gather_pix(d, decode_row(d, k), wg_ty, wg_tx), gn);
+                rb[i] = ld4(p);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) rb[i] = ld4(b_col_ptr<float>(d, z, k0 + bck + BKP * i, n0 + bcc));
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* As = fsm + buf * STAGE;
+        float* Bs = As + A_EL;
+        if (A_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) *reinterpret_cast<float4*>(&As[(rr + 32 * i) * LD + rk]) = ra[i];
+        } else {            // [k][m] in memory -> [m][k] image
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int k = ack + AKP * i;
+                As[(acc_ + 0) * LD + k] = ra[i].x; As[(acc_ + 1) * LD + k] = ra[i].y;
+                As[(acc_ + 2) * LD + k] = ra[i].z; As[(acc_ + 3) * LD + k] = ra[i].w;
+            }
+        }
+        if (B_ROWS) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) *reinterpret_cast<float4*>(&Bs[(rr + 32 * i) * LD + rk]) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = bck + BKP * i;
+                Bs[(bcc + 0) * LD + k] = rb[i].x; Bs[(bcc + 1) * LD + k] = rb[i].y;
+                Bs[(bcc + 2) * LD + k] = rb[i].z; Bs[(bcc + 3) * LD + k] = rb[i].w;
             }
         }
     };
-    fetch(z.kbeg);
-    for (int k0 = z.kbeg; k0 < z.kend; k0 += KS) {
-        __syncthreads();
+
+    f32x4 acc[MI][NI];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (LAYOUT != 2) {
-                As[(q * BK + rk + 0) * LD + rr] = av[q].x; As[(q * BK + rk + 1) * LD + rr] = av[q].y;
-                As[(q * BK + rk + 2) * LD + rr] = av[q].z; As[(q * BK + rk + 3) * LD + rr] = av[q].w;
-            } else {
-                *reinterpret_cast<float4*>(&As[(q * BK + ck) * LD + cc]) = av[q];
-            }
-            if (LAYOUT == 0) {
-                Bs[(q * BK + rk + 0) * LD + rr] = bv[q].x; Bs[(q * BK + rk + 1) * LD + rr] = bv[q].y;
-                Bs[(q * BK + rk + 2) * LD + rr] = bv[q].z; Bs[(q * BK + rk + 3) * LD + rr] = bv[q].w;
-            } else {
-                *reinterpret_cast<float4*>(&Bs[(q * BK + ck) * LD + cc]) = bv[q];
-            }
-        }
-        __syncthreads();
-        if (k0 + KS < z.kend) fetch(k0 + KS);          // in flight under the FMAs below
-#pragma unroll 16
-        for (int k = 0; k < KS; ++k) {
-            float4 a = *reinterpret_cast<const float4*>(&As[k * LD + ty * 4]);
-            float4 b = *reinterpret_cast<const float4*>(&Bs[k * LD + tx * 4]);
-            float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
-        }
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = tapmajor ? d.KH * d.KW * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tiles(z.kbeg);
+        store_tiles(0);
+        if (nk > 1) load_tiles(z.kbeg + BK);
     }
-    const int n = n0 + tx * 4;
-    if (n < d.N) {
+    __syncthreads();
+    const int frow = lane & 15, fk = 4 * (lane >> 4);
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) store_tiles(cur ^ 1);
+        if (it + 2 < nk) load_tiles(z.kbeg + (it + 2) * BK);
+        const float* As = fsm + cur * STAGE;
+        const float* Bs = As + A_EL;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m = m0 + ty * 4 + i;
-            if (m < d.M) epilogue4<float>(d, z, m, n, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            float4 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wr * WM + i * 16 + frow) * LD + kk * 16 + fk]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const float4*>(&Bs[(wc * WN + j * 16 + frow) * LD + kk * 16 + fk]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    // operands swapped like the bf16 kernels: the accumulator holds D[m = lane&15][n = 4*(lane>>4) + reg]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j].x, af[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j].y, af[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j].z, af[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j].w, af[i].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wr * WM + i * 16 + (lane & 15);
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);
+            if (n < d.N) epilogue4<float>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
         }
     }
 }
-
 
 // ----------------------------------------------------------------------------
 // Skinny fp32 linear layer D[m][n] = alpha * sum_k A[m][k] B[n][k] + bias[n] with M <= 32 rows (the batch):
@@ -2183,6 +2276,27 @@ static bool ring_eligible(const mdm_gemm_desc& d) {
     return d.K % 64 == 0;
 }
 
+template <int BM, int BN, int LAYOUT>
+static int launch_f32_mfma_one(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    constexpr int bytes = 2 * (BM + BN) * 36 * 4;
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<BM, BN, LAYOUT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, LAYOUT>), grid, dim3(256), bytes, s, d);
+    return 0;
+}
+template <int BM, int BN>
+static int launch_f32_mfma(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
+    switch (d.layout) {
+        case 0: return launch_f32_mfma_one<BM, BN, 0>(d, grid, s);
+        case 1: return launch_f32_mfma_one<BM, BN, 1>(d, grid, s);
+        default: return launch_f32_mfma_one<BM, BN, 2>(d, grid, s);
+    }
+}
+
 template <int BM, int BN>
 static void launch_bf16(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     switch (d.layout) {
@@ -2282,11 +2396,10 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         }
         hipLaunchKernelGGL(linear_skinny_f32_kernel, dim3((unsigned)cdiv(d.N, 16)), dim3(256), bytes, s, d);
     } else if (d.dtype == MDM_F32) {
-        switch (d.layout) {
-            case 0: hipLaunchKernelGGL((gemm_f32_kernel<0>), grid, dim3(256), 0, s, d); break;
-            case 1: hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, s, d); break;
-            default: hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, s, d); break;
-        }
+        // exact-fp32 MFMA kernel; 128 x 128 tiles when that still gives about one workgroup per CU
+        const bool big32 = d.M >= 128 && d.N >= 128 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * grid.z >= kBigMinTiles;
+        rc = big32 ? launch_f32_mfma<128, 128>(d, dim3((unsigned)((int64_t)cdiv(d.M, 128) * cdiv(d.N, 128)), 1, grid.z), s)
+                   : launch_f32_mfma<64, 64>(d, grid, s);
     } else if (ring_eligible(d) && d.layout == 0 && d.conv &&
                (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0)) && d.C0 <= 4096 && d.C1 <= 4096 &&
                (d.ups == 0 || (d.splitk <= 1 && halo_tile(d) != 0)) && d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
