@@ -184,6 +184,20 @@ int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1,
                           float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, float* ws,
                           void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Fused single-head attention of AttentionBlock.qkv (unet6.py:316-324): o = softmax(q k^T * scale) v over L tokens,
+ * qkv = [N][L][3C] (q | k | v) as project_in writes it (NHWC), o = [N][L][C]; bf16, C in {32, 64, 128, 256},
+ * L % 16 == 0 (mdm_attn_supported).  One forward launch (online softmax over 64-key tiles, the scores never reach
+ * memory), lse[N][L] = log-sum-exp of the scaled scores per query (fp32) is kept for the backward.
+ * Backward: two launches -- dQ (also writes delta[N][L] = sum_d dO*O) and dK/dV -- recomputing P from q, k, lse;
+ * dqkv = [N][L][3C] is written completely (dq | dk | dv), nothing is accumulated.
+ * Replaces both einsums, the softmax and `.contiguous()` of unet6.py:319-324 and their autograd backward.
+ * ------------------------------------------------------------------------- */
+int mdm_attn_supported(int dtype, int L, int C);
+int mdm_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int N, int L, int C, float scale, void* stream);
+int mdm_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                 int N, int L, int C, float scale, void* stream);
+
 /* row softmax of S[rows][L] in place (unet6.py:320-322), and its backward
  * dS = P * (dP - sum_j dP*P) written over dP. */
 int mdm_softmax_fwd(int dtype, void* S, int rows, int L, void* stream);

@@ -1,0 +1,374 @@
+// Fused single-head self-attention for the AttentionBlock of unet6 (reference unet6.py:316-333):
+//     w = softmax(q k^T / sqrt(C)) ;  o = w v          over L = H*W tokens, one head of width C,
+// on qkv = project_in(norm(x)) stored NHWC as [N][L][3C] (q | k | v), bf16.
+//
+// The unfused path (two batched contractions + a softmax launch, S[N][L][L] materialised in HBM; five more
+// launches and dP[N][L][L] in the backward) is replaced by ONE forward kernel and TWO backward kernels that
+// never write the scores: per 64-query tile the keys are walked in tiles of 64 with an online softmax
+// (running max m, running sum l per query), the backward recomputes P from q, k and the saved
+// log-sum-exp.  QK^T, PV and the four backward products run on v_mfma_f32_16x16x32_bf16.
+//
+// Orientation.  Every product is computed TRANSPOSED (operands swapped) so that the query (dQ kernel, forward)
+// or the key (dK/dV kernel) sits on the MFMA lane (lane & 15) and the other index on the accumulator registers:
+//   * row statistics (max, sum, LSE, delta) are lane-local -- two __shfl_xor (16, 32) join the four lane groups;
+//   * the accumulator of the first product IS the B operand of the second one (cvt to bf16, no LDS round trip):
+//     registers r of blocks 2s and 2s+1 of lane group g form k-step s with the key order
+//     k = 8 g + j  <->  key 32 s + (j < 4 ? 4 g + j : 16 + 4 g + j - 4); the A operand of the second product is
+//     read from LDS in the SAME order with ds_read_b64_tr_b16 (4 consecutive rows per read), which also does
+//     the transposition (V^T, K^T, dO^T, Q^T) for free.
+// LDS tiles are [64 rows][C] bf16 with the 32-byte pair index XOR-ed by (row & 7): the transposing reads are
+// conflict-free, the ds_read_b128 row reads 2-way.
+//
+// 256 threads = 4 waves, one per SIMD (the accumulators of the C = 256 backward need the whole register file);
+// wave w owns 16 of the tile's 64 queries (keys in the dK/dV kernel).  L must be a multiple of 16.
+#include "common.h"
+
+namespace mdm {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4_t;
+
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int chunk) {          // byte offset of 16-byte chunk `chunk` of tile row `row`
+    constexpr int PPR = D / 16, MASK = (PPR - 1) < 7 ? (PPR - 1) : 7;
+    return row * (2 * D) + ((((chunk >> 1) ^ (row & MASK)) << 5) | ((chunk & 1) << 4));
+}
+
+// 64 rows x D of src (row pitch ld elements; rows beyond `nrows` repeat the last valid one: they are masked later)
+template <int D>
+__device__ __forceinline__ void load_tile(char* lds, const bf16_t* src, int row0, int nrows, int ld, int t) {
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int idx = t; idx < 64 * CPR; idx += 256) {
+        const int row = idx / CPR, c = idx - row * CPR;
+        int gr = row0 + row;
+        gr = gr < nrows ? gr : nrows - 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)gr * ld + c * 8);
+        *reinterpret_cast<uint4*>(lds + tile_off<D>(row, c)) = v;
+    }
+}
+// row-read fragment: lane -> row r0 + (lane & 15), elements d = 32 ks + 8 (lane >> 4) .. + 7
+template <int D>
+__device__ __forceinline__ bf16x8 frag_row(const char* tile, int r0, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + tile_off<D>(r0 + (lane & 15), ks * 4 + (lane >> 4)));
+}
+// transposed fragment: element j of lane l = tile[row(j)][d0 + (l & 15)], row(j) = 32 s + (j < 4 ? 4 g + j : 16 + 4 g + j - 4), g = l >> 4
+template <int D>
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int s, int d0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int q = i >> 2, p = i & 3;
+    const int r0 = 32 * s + 4 * g + q, r1 = r0 + 16;
+    const int chunk = (d0 >> 3) + (p >> 1), sub = (p & 1) * 8;
+    const char* p0 = tile + tile_off<D>(r0, chunk) + sub;
+    const char* p1 = tile + tile_off<D>(r1, chunk) + sub;
+    bf4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(p0));
+    bf4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf4_t __attribute__((address_space(3)))*)(p1));
+    bf16x4 l4 = *reinterpret_cast<bf16x4*>(&lo), h4 = *reinterpret_cast<bf16x4*>(&hi);
+    bf16x8 f;
+    f[0] = l4[0]; f[1] = l4[1]; f[2] = l4[2]; f[3] = l4[3];
+    f[4] = h4[0]; f[5] = h4[1]; f[6] = h4[2]; f[7] = h4[3];
+    return f;
+}
+// two accumulator blocks (rows 4g+r of 16-row blocks 2s, 2s+1) -> the bf16 B fragment of k-step s
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+    bf16x8 f;
+    f[0] = (short)f2bf(a[0]); f[1] = (short)f2bf(a[1]); f[2] = (short)f2bf(a[2]); f[3] = (short)f2bf(a[3]);
+    f[4] = (short)f2bf(b[0]); f[5] = (short)f2bf(b[1]); f[6] = (short)f2bf(b[2]); f[7] = (short)f2bf(b[3]);
+    return f;
+}
+__device__ __forceinline__ float group_max(float v) {       // over the 4 lane groups that share (lane & 15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v) {
+    uint2 r;
+    r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+constexpr float NEG_BIG = -1.0e30f;
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+                                                       int L, float scale) {
+    constexpr int KS = D / 32, DB = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Kt = lds;
+    char* Vt = lds + 64 * 2 * D;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+    const int n = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * D;
+    const bf16_t* base = qkv + (int64_t)n * L * ld;
+    int qrow = q0 + (lane & 15);
+    const bool q_ok = qrow < L;
+    qrow = q_ok ? qrow : L - 1;
+    bf16x8 Qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qrow * ld + ks * 32 + 8 * g);
+    f32x4 O[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) O[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, lsum = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        __syncthreads();
+        load_tile<D>(Kt, base + D, k0, L, ld, t);
+        load_tile<D>(Vt, base + 2 * D, k0, L, ld, t);
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            s[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Kt, 16 * jb, ks, lane), Qf[ks], s[jb], 0, 0, 0);
+        }
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = k0 + 16 * jb + 4 * g + r < L;
+                s[jb][r] = ok ? s[jb][r] * scale : NEG_BIG;
+                tmax = fmaxf(tmax, s[jb][r]);
+            }
+        tmax = group_max(tmax);
+        const float m_new = fmaxf(m, tmax), alpha = __expf(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[jb][r] - m_new);
+                s[jb][r] = p;
+                rs += p;
+            }
+        rs = group_sum(rs);
+        lsum = lsum * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { O[db][0] *= alpha; O[db][1] *= alpha; O[db][2] *= alpha; O[db][3] *= alpha; }
+        const bf16x8 pf0 = pack_pair(s[0], s[1]), pf1 = pack_pair(s[2], s[3]);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            O[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Vt, 0, 16 * db, lane), pf0, O[db], 0, 0, 0);
+            O[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Vt, 1, 16 * db, lane), pf1, O[db], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        const float inv = 1.f / lsum;
+        bf16_t* orow = o + ((int64_t)n * L + qrow) * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            f32x4 v = O[db];
+            v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+            store4bf(orow + 16 * db + 4 * g, v);
+        }
+        if (g == 0) lse[(int64_t)n * L + qrow] = m + __logf(lsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (and delta)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, float scale) {
+    constexpr int KS = D / 32, DB = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Kt = lds;
+    char* Vt = lds + 64 * 2 * D;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+    const int n = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * D;
+    const bf16_t* base = qkv + (int64_t)n * L * ld;
+    int qrow = q0 + (lane & 15);
+    const bool q_ok = qrow < L;
+    qrow = q_ok ? qrow : L - 1;
+    bf16x8 Qf[KS], dOf[KS];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qrow * ld + ks * 32 + 8 * g);
+        dOf[ks] = *reinterpret_cast<const bf16x8*>(d_o + ((int64_t)n * L + qrow) * D + ks * 32 + 8 * g);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + ((int64_t)n * L + qrow) * D + ks * 32 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl = fmaf(bf2f((bf16_t)dOf[ks][e]), bf2f((bf16_t)of[e]), dl);
+    }
+    dl = group_sum(dl);                               // delta[q] = sum_d dO[q][d] O[q][d]
+    const float ls = lse[(int64_t)n * L + qrow];
+    if (q_ok && g == 0) delta[(int64_t)n * L + qrow] = dl;
+    f32x4 dQ[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dQ[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        __syncthreads();
+        load_tile<D>(Kt, base + D, k0, L, ld, t);
+        load_tile<D>(Vt, base + 2 * D, k0, L, ld, t);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            s[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Kt, 16 * jb, ks, lane), Qf[ks], s[jb], 0, 0, 0);
+                dp[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Vt, 16 * jb, ks, lane), dOf[ks], dp[jb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = k0 + 16 * jb + 4 * g + r < L;
+                const float p = ok ? __expf(s[jb][r] * scale - ls) : 0.f;
+                s[jb][r] = p * (dp[jb][r] - dl) * scale;                   // dS
+            }
+        const bf16x8 f0 = pack_pair(s[0], s[1]), f1 = pack_pair(s[2], s[3]);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            dQ[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Kt, 0, 16 * db, lane), f0, dQ[db], 0, 0, 0);
+            dQ[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Kt, 1, 16 * db, lane), f1, dQ[db], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        bf16_t* row = dqkv + ((int64_t)n * L + qrow) * ld;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) store4bf(row + 16 * db + 4 * g, dQ[db]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv, int L, float scale) {
+    constexpr int KS = D / 32, DB = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Qt = lds;
+    char* Gt = lds + 64 * 2 * D;           // dO tile
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+    const int n = blockIdx.y, kk0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * D;
+    const bf16_t* base = qkv + (int64_t)n * L * ld;
+    int krow = kk0 + (lane & 15);
+    const bool k_ok = krow < L;
+    krow = k_ok ? krow : L - 1;
+    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Kf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)krow * ld + D + ks * 32 + 8 * g);
+        Vf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)krow * ld + 2 * D + ks * 32 + 8 * g);
+    }
+    f32x4 dK[DB], dV[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { dK[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float* lse_n = lse + (int64_t)n * L;
+    const float* del_n = delta + (int64_t)n * L;
+    for (int q0 = 0; q0 < L; q0 += 64) {
+        __syncthreads();
+        load_tile<D>(Qt, base, q0, L, ld, t);
+        load_tile<D>(Gt, d_o + (int64_t)n * L * D, q0, L, D, t);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            s[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Qt, 16 * qb, ks, lane), Kf[ks], s[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Gt, 16 * qb, ks, lane), Vf[ks], dp[qb], 0, 0, 0);
+            }
+        }
+        // lane: key (lane & 15), queries q0 + 16 qb + 4 g + r
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const int qa = q0 + 16 * qb + 4 * g;          // 4 consecutive queries; L % 16 == 0 -> all valid or all invalid
+            const bool ok = qa < L;
+            const float4 l4 = ok ? *reinterpret_cast<const float4*>(lse_n + qa) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 d4 = ok ? *reinterpret_cast<const float4*>(del_n + qa) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = ok ? __expf(s[qb][r] * scale - lq[r]) : 0.f;
+                s[qb][r] = p;                                            // P
+                dp[qb][r] = p * (dp[qb][r] - dq[r]) * scale;             // dS
+            }
+        }
+        const bf16x8 p0 = pack_pair(s[0], s[1]), p1 = pack_pair(s[2], s[3]);
+        const bf16x8 e0 = pack_pair(dp[0], dp[1]), e1 = pack_pair(dp[2], dp[3]);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            dV[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Gt, 0, 16 * db, lane), p0, dV[db], 0, 0, 0);
+            dV[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Gt, 1, 16 * db, lane), p1, dV[db], 0, 0, 0);
+            dK[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Qt, 0, 16 * db, lane), e0, dK[db], 0, 0, 0);
+            dK[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<D>(Qt, 1, 16 * db, lane), e1, dK[db], 0, 0, 0);
+        }
+    }
+    if (k_ok) {
+        bf16_t* row = dqkv + ((int64_t)n * L + krow) * ld;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            store4bf(row + D + 16 * db + 4 * g, dK[db]);
+            store4bf(row + 2 * D + 16 * db + 4 * g, dV[db]);
+        }
+    }
+}
+
+template <int D>
+static int attn_launch(int which, const bf16_t* qkv, bf16_t* o, const bf16_t* d_o, float* lse, float* delta, bf16_t* dqkv,
+                       int N, int L, float scale, hipStream_t s) {
+    constexpr int bytes = 2 * 64 * 2 * D;
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    dim3 grid((unsigned)cdiv(L, 64), (unsigned)N);
+    if (which == 0) {
+        hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), bytes, s, qkv, o, lse, L, scale);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), bytes, s, qkv, (const bf16_t*)o, d_o, (const float*)lse, delta, dqkv, L, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, dim3(256), bytes, s, qkv, d_o, (const float*)lse, (const float*)delta, dqkv, L, scale);
+    }
+    return launch_status("attention");
+}
+static int attn_dispatch(int which, int C, const bf16_t* qkv, bf16_t* o, const bf16_t* d_o, float* lse, float* delta, bf16_t* dqkv,
+                         int N, int L, float scale, hipStream_t s) {
+    switch (C) {
+        case 32: return attn_launch<32>(which, qkv, o, d_o, lse, delta, dqkv, N, L, scale, s);
+        case 64: return attn_launch<64>(which, qkv, o, d_o, lse, delta, dqkv, N, L, scale, s);
+        case 128: return attn_launch<128>(which, qkv, o, d_o, lse, delta, dqkv, N, L, scale, s);
+        case 256: return attn_launch<256>(which, qkv, o, d_o, lse, delta, dqkv, N, L, scale, s);
+    }
+    set_error("attention: head width C=%d is not one of 32, 64, 128, 256", C);
+    return -1;
+}
+
+}  // namespace mdm
+using namespace mdm;
+
+extern "C" int mdm_attn_supported(int dtype, int L, int C) {
+    return dtype == MDM_BF16 && L > 0 && L % 16 == 0 && (C == 32 || C == 64 || C == 128 || C == 256) ? 1 : 0;
+}
+extern "C" int mdm_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int N, int L, int C, float scale, void* stream) {
+    MDM_REQUIRE(mdm_attn_supported(dtype, L, C), "attn_fwd: unsupported dtype %d / L %d / C %d (use the contraction path)", dtype, L, C);
+    MDM_REQUIRE(qkv && o && lse && N > 0, "attn_fwd: bad arguments");
+    return attn_dispatch(0, C, (const bf16_t*)qkv, (bf16_t*)o, nullptr, lse, nullptr, nullptr, N, L, scale, pick_stream(stream));
+}
+extern "C" int mdm_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                            int N, int L, int C, float scale, void* stream) {
+    MDM_REQUIRE(mdm_attn_supported(dtype, L, C), "attn_bwd: unsupported dtype %d / L %d / C %d (use the contraction path)", dtype, L, C);
+    MDM_REQUIRE(qkv && o && d_o && lse && delta && dqkv && N > 0, "attn_bwd: bad arguments");
+    return attn_dispatch(1, C, (const bf16_t*)qkv, (bf16_t*)const_cast<void*>(o), (const bf16_t*)d_o, const_cast<float*>(lse), delta,
+                         (bf16_t*)dqkv, N, L, scale, pick_stream(stream));
+}

@@ -52,6 +52,9 @@ _PROTOS = {
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], i32),
     "mdm_groupnorm_bwd_add": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp], i32),
+    "mdm_attn_supported": ([i32, i32, i32], i32),
+    "mdm_attn_fwd": ([i32, vp, vp, vp, i32, i32, i32, f32, vp], i32),
+    "mdm_attn_bwd": ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),
     "mdm_softmax_fwd": ([i32, vp, i32, i32, vp], i32),
     "mdm_softmax_bwd": ([i32, vp, vp, i32, i32, vp], i32),
     "mdm_timestep_embedding": ([vp, i32, i32, vp, vp], i32),

@@ -184,6 +184,18 @@ def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, ds
          ptr(sum_all), ptr(ws), stream())
 
 
+def attn_supported(dt, L, C):
+    return bool(_lib.load().mdm_attn_supported(dt, L, C))
+
+
+def attn_fwd(dt, qkv, o, lse, N, L, C, scale):
+    call("mdm_attn_fwd", dt, ptr(qkv), ptr(o), ptr(lse), N, L, C, float(scale), stream())
+
+
+def attn_bwd(dt, qkv, o, do, lse, delta, dqkv, N, L, C, scale):
+    call("mdm_attn_bwd", dt, ptr(qkv), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dqkv), N, L, C, float(scale), stream())
+
+
 def softmax_fwd(dt, S, rows, L):
     call("mdm_softmax_fwd", dt, ptr(S), rows, L, stream())
 

@@ -327,6 +327,11 @@ class _AttnCore:
     def fwd(self):
         n, q, o = self.net, self.qkv, self.out
         N, L, C = q.N, q.P, o.C
+        self.fused = ops.attn_supported(n.dt, L, C)
+        if self.fused:               # one kernel, the scores never reach memory (csrc/attn.hip)
+            self.lse = n.alloc((N, L), torch.float32)
+            ops.attn_fwd(n.dt, q.data, o.data, self.lse, N, L, C, 1.0 / math.sqrt(C))
+            return
         self.S = n.alloc((N, L, L), n.tdtype)
         d = q.data.view(N, L, 3 * C)
         sc = 1.0 / math.sqrt(C)
@@ -340,6 +345,10 @@ class _AttnCore:
         do = n.grad_for_read(o)
         dqkv, acc, _ = n.grad_for_write(q)
         assert acc == 0
+        if self.fused:
+            self.delta = n.alloc((N, L), torch.float32)
+            ops.attn_bwd(n.dt, q.data, o.data, do, self.lse, self.delta, dqkv, N, L, C, 1.0 / math.sqrt(C))
+            return
         d = q.data.view(N, L, 3 * C)
         g = dqkv.view(N, L, 3 * C)
         sc = 1.0 / math.sqrt(C)

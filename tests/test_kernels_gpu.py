@@ -513,3 +513,42 @@ def test_groupnorm_forward_fused_into_the_producing_conv(case):
     assert _relerr(zo, _nhwc(z)) < _tol(dt)
     yg = y.reshape(N, 32, -1)
     assert _relerr(stats[..., 0], yg.mean(-1)) < 2e-2 and _relerr(stats[..., 1], 1.0 / torch.sqrt(yg.var(-1, unbiased=False) + 1e-6)) < 2e-2
+
+
+@pytest.mark.parametrize("N,L,C", [(3, 16, 256), (2, 64, 256), (2, 256, 128), (1, 1024, 128), (2, 64, 32), (1, 256, 64), (2, 48, 64)])
+def test_fused_attention_forward_and_backward(N, L, C):
+    """csrc/attn.hip (unet6.py:316-324 and its autograd backward): o = softmax(q k^T / sqrt(C)) v on the NHWC qkv tensor,
+    online softmax over 64-key tiles (L = 1024: 16 tiles; L = 16 / 48: partial tiles), dq / dk / dv from the saved
+    log-sum-exp -- against fp64 torch on the same bf16-rounded inputs."""
+    import math
+    from mdm import ops
+    g = torch.Generator().manual_seed(100 + L + C)
+    dev = _dev()
+    qkv = _q(torch.randn(N, L, 3 * C, generator=g) * 1.5, "bf16")
+    qkv[0, 0, C:2 * C] *= 6.0                      # one key that dominates some rows: the running max jumps inside the walk
+    qkv = _q(qkv, "bf16")
+    do = _q(torch.randn(N, L, C, generator=g), "bf16")
+    scale = 1.0 / math.sqrt(C)
+    assert ops.attn_supported(1, L, C)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]
+    s = torch.einsum("nlc,nmc->nlm", q, k) * scale
+    want_o = torch.einsum("nlm,nmc->nlc", torch.softmax(s, -1), v)
+    (want_o * do.double()).sum().backward()
+    want_lse = torch.logsumexp(s, -1)
+    d_qkv = _up(qkv, "bf16")
+    o = torch.full((N, L, C), float("nan"), device=dev, dtype=torch.bfloat16)
+    lse = torch.full((N, L), float("nan"), device=dev)
+    ops.attn_fwd(1, d_qkv, o, lse, N, L, C, scale)
+    torch.cuda.synchronize()
+    assert _relerr(o, want_o.detach().float()) < 1e-2, _relerr(o, want_o.detach().float())
+    assert float((lse.cpu() - want_lse.detach().float()).abs().max()) < 2e-2
+    dq = torch.full((N, L, 3 * C), float("nan"), device=dev, dtype=torch.bfloat16)
+    delta = torch.full((N, L), float("nan"), device=dev)
+    ops.attn_bwd(1, d_qkv, o, _up(do, "bf16"), lse, delta, dq, N, L, C, scale)
+    torch.cuda.synchronize()
+    gx = x.grad.float()
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        err = _relerr(dq[..., sl], gx[..., sl])
+        assert err < 2.5e-2, (name, err)
+    assert bool(torch.isfinite(dq.float()).all())

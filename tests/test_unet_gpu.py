@@ -105,8 +105,15 @@ CFG_WIDE = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=
                                                          # group -> whole-image halo tiles, GroupNorm backward fused into the data gradient
 
 
+CFG4_FULL = dict(in_channels=4, hid_channels=128, out_channels=4, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
+                 apply_attn=[True, True, True, True])     # BASELINE cfg4 at FULL width: 38.72 M parameters, attention L = 1024 (d 128), 256, 64, 16 (d 256)
+CFG3_FULL = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
+                 apply_attn=[False, False, True, False])  # BASELINE cfg3: the unet6 preset on 64x64 (GroupNorm over 16 384-element groups, L = 256)
+
+
 @pytest.mark.parametrize("name,cfg,hw,n", [("cfg4_attn_everywhere_C4", CFG4_TINY, 32, 2), ("cfg3_64x64", CFG3_TINY, 64, 2),
-                                           ("preset_widths_16x16", CFG_WIDE, 16, 4)])
+                                           ("preset_widths_16x16", CFG_WIDE, 16, 4), ("cfg4_full_width", CFG4_FULL, 32, 2),
+                                           ("cfg3_full_width_64x64", CFG3_FULL, 64, 2)])
 @pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
 def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, tol_g):
     from mdm import ops
