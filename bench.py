@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--wgrad-group-mb", type=float, default=None, help=argparse.SUPPRESS)      # experiments only
     ap.add_argument("--overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
     opt_ = ap.parse_args()
@@ -234,7 +235,7 @@ def main():
     sched = mdm.Scheduler(args, device=dev)
     sched.update_ddpm_num_steps(1000)
     used = sched.get_timesteps_epoch(0, 1)
-    comm = GradComm() if world > 1 else None
+    comm = GradComm(wire=opt_.grad_wire) if world > 1 else None
     step = TrainStep(model, sched, args, optim, ema, mean_shift=True, comm=comm)
     g = torch.Generator().manual_seed(100 + rank)
     step.x0.copy_(torch.rand(N, 3, 32, 32, generator=g) * 2 - 1)          # synthetic batch, resident in HBM

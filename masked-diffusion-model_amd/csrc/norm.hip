@@ -246,23 +246,24 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
 // v = t % VB (its 8-channel vector) and the sums run over the 256/VB pixel lanes of each column.
 // (The first version reduced with __shfl_xor: 4 ds_bpermute round trips per value, 128 per thread in the
 // backward -- 20k cycles of a 36k-cycle kernel.)  scratch: K * CS_PITCH floats; out[k * VB + v].
-constexpr int CS_PITCH = 260;
-template <int K>
+template <int K, int NT = 256>
 __device__ __forceinline__ void block_colsum(const float (&val)[K], float* scratch, float* out, int t, int VB, int PL) {
+    constexpr int CS_PITCH = NT + 4;
 #pragma unroll
     for (int k = 0; k < K; ++k) scratch[k * CS_PITCH + t] = val[k];
     __syncthreads();
     const int cols = K * VB;                       // <= 256
     int tpc = 1;                                   // threads per column (power of two)
-    while (tpc * 2 * cols <= 256) tpc *= 2;
+    while (tpc * 2 * cols <= NT) tpc *= 2;
     const int col = t / tpc, part = t - col * tpc;
     float sum = 0.f;
     if (col < cols) {
         const int k = col / VB, v = col - k * VB;
-        const int per = (PL + tpc - 1) / tpc;
-        const int l0 = part * per, l1 = min(PL, l0 + per);
+        // the tpc threads of a column take the pixel lanes INTERLEAVED (l = part, part + tpc, ...): neighbouring lanes then
+        // read neighbouring LDS words.  (Contiguous shares put the threads of a column a multiple of 64 words apart --
+        // 8-way bank conflicts, 62 % of the GroupNorm kernels' LDS cycles by SQ_LDS_BANK_CONFLICT.)
         const float* src = scratch + k * CS_PITCH + v;
-        for (int l = l0; l < l1; ++l) sum += src[l * VB];
+        for (int l = part; l < PL; l += tpc) sum += src[l * VB];
     }
     for (int o = 1; o < tpc; o <<= 1) sum += __shfl_xor(sum, o, 64);     // <= 3 steps on ONE value
     if (col < cols && part == 0) out[col] = sum;
@@ -299,12 +300,15 @@ __device__ __forceinline__ unsigned long long nstamp_now() {
 // workgroups to pull HBM bandwidth (128 for a 32x32x128 map: 14/24 us fwd/bwd against ~6/9 us of traffic),
 // so there the pixels are cut into gridDim.z chunks: MODE 1 = statistics of one chunk -> partials in ws
 // [image][chunk][group][2] (plain stores, nothing to zero, fixed summation order), MODE 2 = apply.
-template <int NP, int MODE>
-__global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
+// NT = threads per workgroup: 512 on the larger slices (the kernels are VALU- and latency-bound at one wave per SIMD:
+// twice the waves per workgroup halve each thread's serial share of exp / rcp work)
+template <int NP, int MODE, int NT = 256>
+__global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          float eps, const float* gamma, const float* beta, int silu, bf16_t* y,
                                                          float* stats, float* ws) {
+    constexpr int CS_PITCH = NT + 4;
     const int C = C0 + C1, cpg = C / G;
-    const int VB = CBLK / 8, PL = 256 / VB;
+    const int VB = CBLK / 8, PL = NT / VB;
     const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
         }
     }
     if (MODE != 2) {
-        block_colsum<16>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
+        block_colsum<16, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
         if (t < CBLK && cb + t < C) {
             const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
             atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
@@ -407,14 +411,15 @@ __global__ __launch_bounds__(256) void gn_fwd_reg_kernel(const bf16_t* s0, int C
     }
 }
 
-template <int NP, int MODE>
-__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
+template <int NP, int MODE, int NT = 256>
+__global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          const float* gamma, const float* beta, int silu, const bf16_t* dy,
                                                          const float* stats, bf16_t* d0, const bf16_t* add0, bf16_t* d1, const bf16_t* add1,
                                                          float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all,
                                                          float* ws) {
+    constexpr int CS_PITCH = NT + 4;
     const int C = C0 + C1, cpg = C / G;
-    const int VB = CBLK / 8, PL = 256 / VB;
+    const int VB = CBLK / 8, PL = NT / VB;
     const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
     const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
     const int ng = CBLK / cpg, g0 = cb / cpg;
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
         }
     }
     if (MODE != 2) {
-        block_colsum<32>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
+        block_colsum<32, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
         if (t < CBLK && cb + t < C) {
             const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
             atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reg_kernel(const bf16_t* s0, int C
         }
     }
     if (sum_img || sum_all) {            // uniform
-        block_colsum<8>(sx, scratch, csum, t, VB, PL);
+        block_colsum<8, NT>(sx, scratch, csum, t, VB, PL);
         if (t < CBLK && cb + t < C) {
             const float r = csum[(t & 7) * VB + (t >> 3)];
             if (sum_img) {
@@ -769,12 +774,12 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     dim3 grid(N, cdiv(C, cblk));
-    const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane
+    const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane of a 256-thread workgroup
     if (dtype == MDM_BF16 && np <= 16) {
-#define GN_FWD_REG(NPV) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
-                                           (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
-        if (np <= 1) GN_FWD_REG(1); else if (np <= 2) GN_FWD_REG(2); else if (np <= 4) GN_FWD_REG(4);
-        else if (np <= 8) GN_FWD_REG(8); else GN_FWD_REG(16);
+#define GN_FWD_REG(NPV, NT) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV, 0, NT>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                               (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
+        if (np <= 1) GN_FWD_REG(1, 256); else if (np <= 2) GN_FWD_REG(2, 256); else if (np <= 4) GN_FWD_REG(2, 512);
+        else if (np <= 8) GN_FWD_REG(4, 512); else GN_FWD_REG(8, 512);
 #undef GN_FWD_REG
         return launch_status("groupnorm_fwd");
     }
@@ -794,12 +799,12 @@ extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const 
     dim3 grid(N, cdiv(C, cblk));
     const int np = cdiv(P, 256 / (cblk / 8));
     if (dtype == MDM_BF16 && np <= 16) {
-#define GN_BWD_REG(NPV) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
-                                           (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
-                                           (bf16_t*)dst0, (const bf16_t*)add0, (bf16_t*)dst1, (const bf16_t*)add1, dgamma, dbeta,       \
-                                           sum_img, sum_ld, sum_all, ws)
-        if (np <= 1) GN_BWD_REG(1); else if (np <= 2) GN_BWD_REG(2); else if (np <= 4) GN_BWD_REG(4);
-        else if (np <= 8) GN_BWD_REG(8); else GN_BWD_REG(16);
+#define GN_BWD_REG(NPV, NT) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV, 0, NT>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
+                                               (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
+                                               (bf16_t*)dst0, (const bf16_t*)add0, (bf16_t*)dst1, (const bf16_t*)add1, dgamma, dbeta,       \
+                                               sum_img, sum_ld, sum_all, ws)
+        if (np <= 1) GN_BWD_REG(1, 256); else if (np <= 2) GN_BWD_REG(2, 256); else if (np <= 4) GN_BWD_REG(2, 512);
+        else if (np <= 8) GN_BWD_REG(4, 512); else GN_BWD_REG(8, 512);
 #undef GN_BWD_REG
         return launch_status("groupnorm_bwd");
     }

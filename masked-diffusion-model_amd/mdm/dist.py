@@ -33,14 +33,23 @@ def init_from_env(backend=None):
 
 
 class GradComm:
-    def __init__(self, group=None, bucket_bytes=32 << 20, tail_bytes=4 << 20):
+    """wire="f32": all-reduce the fp32 gradient slices in place (what accelerate/DDP do for the reference: fp32 master
+    gradients, bit-identical replicas).  wire="bf16": each bucket is rounded to bf16 into a staging buffer, all-reduced
+    there and widened back -- half the bytes on xGMI (71.5 MB instead of 143 MB per step at cfg2), at the
+    price of one rounding of every gradient element before the sum (replicas stay bit-identical: every rank widens the
+    same reduced values).  Default fp32: at cfg2 the exchange hides behind the backward except for the last bucket."""
+
+    def __init__(self, group=None, bucket_bytes=32 << 20, tail_bytes=4 << 20, wire="f32"):
+        assert wire in ("f32", "bf16"), wire
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_bytes = bucket_bytes
         self.tail_bytes = min(tail_bytes, bucket_bytes)
+        self.wire = wire
         self.buckets = []        # (lo, hi) element ranges of the flat gradient buffer, in completion order
         self._handles = []
+        self._stage = None       # bf16 staging copy of the flat gradient buffer (wire="bf16")
 
     # ---- planning --------------------------------------------------------------------------
     @staticmethod
@@ -80,11 +89,22 @@ class GradComm:
         if self.world == 1:
             return
         lo, hi = self.buckets[i]
-        self._handles.append(dist.all_reduce(G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.wire == "bf16":
+            if self._stage is None or self._stage.numel() != G.numel():
+                self._stage = torch.empty(G.numel(), dtype=torch.bfloat16, device=G.device)
+            self._Gref = G
+            st = self._stage[lo:hi]
+            st.copy_(G[lo:hi])                                   # round once, on the compute stream, behind the bucket's kernels
+            h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._handles.append((h, lo, hi))
+            return
+        self._handles.append((dist.all_reduce(G[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
 
-    def wait_all(self):
-        for h in self._handles:
+    def wait_all(self, G=None):
+        for h, lo, hi in self._handles:
             h.wait()             # on NCCL/RCCL: stream-level wait, the host does not block
+            if lo is not None:
+                (G if G is not None else self._Gref)[lo:hi].copy_(self._stage[lo:hi])       # widen the reduced bucket back
         self._handles = []
 
     def allreduce_all(self, G):

@@ -250,6 +250,6 @@ class TrainStep:
             self.ev_side.record(self.side)
             main.wait_event(self.ev_side)
         if self.comm is not None:
-            self.comm.wait_all()
+            self.comm.wait_all(self.model.store.G)
         go(tail)
         return self.loss

@@ -32,7 +32,7 @@ class Trainer:
         self.Sampler = Sampler(self.dataset, self.args, self.Scheduler, self.dataset_hist)
         self.global_step = 0
         self.timesteps_used_epoch = None
-        comm = GradComm() if getattr(accelerator, "num_processes", 1) > 1 else None
+        comm = GradComm(wire=getattr(args, "grad_wire_dtype", "f32")) if getattr(accelerator, "num_processes", 1) > 1 else None
         ema = ema_model if getattr(args, "use_ema", False) else None
         self.step = TrainStep(model, self.Scheduler, args, optimizer, ema, mean_shift=self.mean_shift, comm=comm)
         self.loss_names = ["train_loss"]

@@ -300,6 +300,122 @@ def gen_train_step(scheduler_mod, unet6, out):
             out[f"step_{name}_w::{k}"] = npy(sd[k])
 
 
+SLICE = dict(in_channels=3, hid_channels=256, out_channels=3, ch_multipliers=[1], num_res_blocks=1,
+             apply_attn=[False])            # one level at the preset's width (256 channels): res blocks 256->256, 512->256, attention d=256
+
+
+def gen_blocks(unet6, out):
+    """Pieces in isolation (reference unet6.py:296-362, 257-272) and a preset-WIDTH slice, forward + backward."""
+    g = torch.Generator().manual_seed(31)
+    # ResidualBlock 32 -> 64 (1x1 skip), 8x8
+    rb = unet6.ResidualBlock(32, 64, embed_dim=128)
+    for k, v in rb.state_dict().items():
+        v.copy_(torch.randn(v.shape, generator=g) * (0.1 if v.dim() > 1 else 0.05) + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
+    x = torch.randn(2, 32, 8, 8, generator=g).requires_grad_(True)
+    te = torch.randn(2, 128, generator=g).requires_grad_(True)
+    y = rb(x, te)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out["rb_x"] = npy(x); out["rb_temb"] = npy(te); out["rb_y"] = npy(y); out["rb_gy"] = npy(gy)
+    out["rb_gx"] = npy(x.grad); out["rb_gtemb"] = npy(te.grad)
+    for k, v in rb.named_parameters():
+        out["rb_p::" + k] = npy(v); out["rb_g::" + k] = npy(v.grad)
+    # AttentionBlock C = 64, 8x8 (L = 64)
+    ab = unet6.AttentionBlock(64)
+    for k, v in ab.state_dict().items():
+        v.copy_(torch.randn(v.shape, generator=g) * (0.15 if v.dim() > 1 else 0.05) + (1.0 if "norm" in k and k.endswith("weight") else 0.0))
+    x = torch.randn(2, 64, 8, 8, generator=g).requires_grad_(True)
+    y = ab(x)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out["ab_x"] = npy(x); out["ab_y"] = npy(y); out["ab_gy"] = npy(gy); out["ab_gx"] = npy(x.grad)
+    for k, v in ab.named_parameters():
+        out["ab_p::" + k] = npy(v); out["ab_g::" + k] = npy(v.grad)
+    # SamePad2d(3, 2) + stride-2 conv: VALUES (the downsample of unet6.py:436-440)
+    conv = unet6.Conv2d(16, 24, 3, 2)
+    for k, v in conv.state_dict().items():
+        v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    x = torch.randn(2, 16, 8, 8, generator=g)
+    with torch.no_grad():
+        out["sp_x"] = npy(x); out["sp_pad"] = npy(unet6.SamePad2d(3, 2)(x)); out["sp_y"] = npy(conv(unet6.SamePad2d(3, 2)(x)))
+    for k, v in conv.state_dict().items():
+        out["sp_p::" + k] = npy(v)
+    # preset-width slice: whole (small) net at hid = 256 on 8x8, all gradients summarised + a subset stored
+    m = build_ref_unet(unet6, SLICE, seed=9)
+    x = (torch.rand(2, 3, 8, 8, generator=g) * 2 - 1).requires_grad_(True)
+    t = torch.tensor([11.0, 640.0])
+    y = m(x, t)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out["slice_x"] = npy(x); out["slice_t"] = npy(t); out["slice_y"] = npy(y); out["slice_gy"] = npy(gy); out["slice_gx"] = npy(x.grad)
+    sd = dict(m.named_parameters())
+    out["slice_gnorm"] = np.array(float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values()))))
+    out["slice_gnorms"] = np.array([float(v.grad.norm()) for v in sd.values()])
+    out["slice_keys"] = np.array(list(sd.keys()))
+    for k in ("in_conv.weight", "downsamples.level_0.0.conv1.weight", "downsamples.level_0.0.norm2.weight", "middle.1.project_in.weight",
+              "middle.1.project_out.bias", "middle.2.conv2.weight", "upsamples.level_0.0.skip.weight", "upsamples.level_0.1.conv1.bias",
+              "upsamples.level_0.1.fc.weight", "out_conv.2.weight"):
+        gk = sd[k].grad
+        out["slice_g::" + k] = npy(gk if gk.numel() < 100000 else gk[:16])       # big filters: the first 16 output channels
+
+
+def gen_sampler_long(scheduler_mod, sampler_mod, unet6, out):
+    """10-step trajectories (all 11 history tensors) and 50-step ones (final sample + every 10th history slot)."""
+    i = 0
+    for T in (10, 50):
+        for dep, mode, sel, ch, kind, st in (("independent", "base_momentum", "thresholding", "1-channel", "linear", "noise_with_perturbation"),
+                                             ("dependent_prev", "base_sampling", "thresholding", "3-channel", "exponential", "noise_reduction")):
+            a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=T, select_degrade_pixel=sel, degrade_channel=ch,
+                          shift_type=st, sampling_mask_dependency=dep, momentum_adaptive=mode, sample_num=2,
+                          sample_latent_shape="normal", noise_mean=0.1)
+            s = scheduler_mod.Scheduler(a); s.update_ddpm_num_steps(T)
+            ts = s.get_timesteps_epoch(0, 1)
+            model = _Wrap(build_ref_unet(unet6, TINY)).eval()
+            seed_all(600 + i)
+            x0, hist = sampler_mod.Sampler(None, a, s, [None] * 3).sample(model, ts)
+            out[f"long{i}_cfg"] = np.array([dep, mode, sel, str(ch), kind, st, str(T)])
+            out[f"long{i}_ts"] = np.array(ts)
+            out[f"long{i}_x0"] = npy(x0)
+            h = np.stack([npy(v) for v in hist])
+            out[f"long{i}_hist"] = h if T == 10 else h[:, ::10]
+            i += 1
+    out["long_n"] = np.array(i)
+
+
+def gen_train_grads(scheduler_mod, unet6, out):
+    """The gradient tensors of one real mean-shift `_run_batch` (before clipping) and the clipping norm."""
+    import accelerate
+    import trainer_masked_mean_shift as mod
+    tmp = tempfile.mkdtemp()
+    dirs = types.SimpleNamespace(list_dir={"train_loss": tmp, "checkpoint": tmp, "ema_sample_img": tmp})
+    g = torch.Generator().manual_seed(23)
+    x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=10, shift_type="noise_with_perturbation", loss_weight_use=True,
+                  batch_size=4, sample_num=2, sample_latent_shape="zero")
+    model = _Wrap(build_ref_unet(unet6, TINY))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    lr_s = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0)
+    acc = accelerate.Accelerator(cpu=True)
+    grads = {}
+    orig = acc.clip_grad_norm_
+
+    def rec(params, max_norm, *aa, **kk):
+        for k, v in model.net.named_parameters():
+            grads[k] = v.grad.detach().clone()
+        grads["__norm__"] = orig(model.parameters(), max_norm, *aa, **kk)
+        return grads["__norm__"]
+    acc.clip_grad_norm_ = rec
+    tr = mod.Trainer(a, None, None, [None] * 3, model, None, opt, lr_s, acc)
+    a.updated_ddpm_num_steps = tr.Scheduler.update_ddpm_num_steps(a.ddpm_num_steps)
+    tr.timesteps_used_epoch = tr.Scheduler.get_timesteps_epoch(0, 1)
+    seed_all(501)
+    loss = tr._run_batch(0, (x0, None, None), 0, 1, 0, dirs, None)
+    out["tg_x0"] = npy(x0); out["tg_loss"] = np.array(loss, dtype=np.float64); out["tg_norm"] = np.array(float(grads.pop("__norm__")))
+    out["tg_xin"] = npy(tr.shifted_degrade_img)
+    for k, v in grads.items():
+        out["tg_g::" + k] = npy(v)
+
+
 def main():
     _stub_modules()
     sys.path.insert(0, REF)
@@ -314,6 +430,9 @@ def main():
         "unet": lambda o: gen_unet(unet6, o),
         "sampler": lambda o: gen_sampler(scheduler_mod, sampler_mod, unet6, o),
         "train_step": lambda o: gen_train_step(scheduler_mod, unet6, o),
+        "blocks": lambda o: gen_blocks(unet6, o),
+        "sampler_long": lambda o: gen_sampler_long(scheduler_mod, sampler_mod, unet6, o),
+        "train_grads": lambda o: gen_train_grads(scheduler_mod, unet6, o),
     }
     only = sys.argv[1:]
     for name, fn in jobs.items():

@@ -192,6 +192,14 @@ for i in range(len(comm.buckets)):
 comm.wait_all()
 want = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world))
 assert torch.equal(flat, want), "bucketed all-reduce"
+# (a') the same through the bf16 wire format (values chosen exactly representable: the sums must be exact too)
+comm3 = GradComm(bucket_bytes=4 * 300, wire="bf16")
+comm3.buckets = [(500, 1000), (0, 500)]
+flat = (torch.arange(1000) % 64).float() * (rank + 1)
+for i in range(2):
+    comm3.reduce_bucket(i, flat)
+comm3.wait_all(flat)
+assert torch.equal(flat, (torch.arange(1000) % 64).float() * sum(r + 1 for r in range(world))), "bf16-wire all-reduce"
 # (b) DP gradient equivalence on the oracle model: mean over ranks of shard-mean grads == full-batch grad
 g = torch.Generator().manual_seed(5)
 x = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1

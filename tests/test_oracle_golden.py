@@ -194,3 +194,123 @@ def test_train_step(golden, name):
         if k.startswith(f"step_{name}_w::"):
             # one AdamW step moves every weight by ~lr regardless of gradient scale, so compare tightly
             assert np.allclose(sd[k.split("::")[1]].detach().numpy(), g[k], rtol=0, atol=2e-5), k
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures (tests/golden/make_golden.py: blocks, sampler_long, train_grads)
+def _close(a, b, rtol=1e-3, floor=1e-4):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.allclose(a, b, rtol=rtol, atol=floor * max(1.0, np.abs(b).max()))
+
+
+def test_residual_block_in_isolation(golden):
+    """reference unet6.py:336-362 -- forward, input / time-embedding gradients and every parameter gradient."""
+    from oracle.unet_ref import res_block
+    g = golden("blocks")
+    p = {"b." + k.split("::")[1]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("rb_p::")}
+    x, te = T(g["rb_x"]).requires_grad_(True), T(g["rb_temb"]).requires_grad_(True)
+    y = res_block(x, te, p, "b")
+    assert _close(y.detach(), g["rb_y"], 1e-4, 2e-5)
+    (y * T(g["rb_gy"])).sum().backward()
+    assert _close(x.grad, g["rb_gx"]) and _close(te.grad, g["rb_gtemb"])
+    for k in g.files:
+        if k.startswith("rb_g::"):
+            assert _close(p["b." + k.split("::")[1]].grad, g[k]), k
+
+
+def test_attention_block_in_isolation(golden):
+    """reference unet6.py:296-333 (einsum attention over L = 64 tokens)."""
+    from oracle.unet_ref import attn_block
+    g = golden("blocks")
+    p = {"b." + k.split("::")[1]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("ab_p::")}
+    x = T(g["ab_x"]).requires_grad_(True)
+    y = attn_block(x, p, "b")
+    assert _close(y.detach(), g["ab_y"], 1e-4, 2e-5)
+    (y * T(g["ab_gy"])).sum().backward()
+    assert _close(x.grad, g["ab_gx"])
+    for k in g.files:
+        if k.startswith("ab_g::"):
+            assert _close(p["b." + k.split("::")[1]].grad, g[k]), k
+
+
+def test_samepad_stride2_conv_values(golden):
+    """reference unet6.py:257-272 + 438-440: the padded tensor and the stride-2 conv output, value for value."""
+    import torch.nn.functional as F
+    g = golden("blocks")
+    x = T(g["sp_x"])
+    pad = same_pad_stride2(x)
+    assert np.array_equal(pad.numpy(), g["sp_pad"])
+    y = F.conv2d(pad, T(g["sp_p::weight"]), T(g["sp_p::bias"]), stride=2)
+    assert _close(y, g["sp_y"], 1e-5, 1e-6)
+
+
+def test_preset_width_slice_forward_backward(golden):
+    from golden.make_golden import SLICE
+    g = golden("blocks")
+    m = UNetRef(SLICE, random_params(SLICE, 9))
+    x = T(g["slice_x"]).requires_grad_(True)
+    y = m(x, T(g["slice_t"])).sample
+    assert _close(y.detach(), g["slice_y"], 1e-4, 2e-5)
+    (y * T(g["slice_gy"])).sum().backward()
+    assert _close(x.grad, g["slice_gx"])
+    grads = {k: p.grad for k, p in zip(m.keys, m.plist)}
+    assert list(g["slice_keys"]) == m.keys
+    assert np.allclose([float(grads[k].norm()) for k in m.keys], g["slice_gnorms"], rtol=2e-3, atol=1e-5)
+    for k in g.files:
+        if k.startswith("slice_g::"):
+            want = g[k]
+            assert _close(grads[k.split("::")[1]][:want.shape[0]], want), k
+
+
+def test_sampler_trajectories_10_and_50_steps(golden):
+    g = golden("sampler_long")
+    for i in range(int(g["long_n"])):
+        dep, mode, sel, ch, kind, st, Tn = [str(v) for v in g[f"long{i}_cfg"]]
+        Tn = int(Tn)
+        a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=Tn, select_degrade_pixel=sel, degrade_channel=ch,
+                      shift_type=st, sampling_mask_dependency=dep, momentum_adaptive=mode, sample_num=2,
+                      sample_latent_shape="normal", noise_mean=0.1)
+        s = S.SchedulerRef(a)
+        s.update_ddpm_num_steps(Tn)
+        ts = s.get_timesteps_epoch(0, 1)
+        assert ts == list(g[f"long{i}_ts"])
+        seed_all(600 + i)
+        x0, hist = SamplerRef(None, a, s, [None] * 3).sample(UNetRef(TINY).eval(), ts)
+        ref = g[f"long{i}_hist"]
+        h = np.stack([v.numpy() for v in hist])
+        h = h if Tn == 10 else h[:, ::10]
+        assert np.array_equal(h[1], ref[1]) and np.array_equal(h[6], ref[6]), i          # shifts and masks: bit-exact
+        for j in range(11):
+            sc = max(1.0, float(np.abs(ref[j]).max()))
+            assert np.abs(h[j] - ref[j]).max() < 2e-4 * sc, (i, j)
+        rel = np.linalg.norm(x0.numpy() - g[f"long{i}_x0"]) / np.linalg.norm(g[f"long{i}_x0"])
+        assert rel < 1e-4, (i, rel)
+
+
+def test_train_step_gradient_tensors(golden):
+    """Every parameter gradient of one real mean-shift `_run_batch` (captured before clipping) and the clipping norm."""
+    g = golden("train_grads")
+    a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=10, shift_type="noise_with_perturbation", loss_weight_use=True,
+                  batch_size=4)
+    s = S.SchedulerRef(a)
+    s.update_ddpm_num_steps(10)
+    model = UNetRef(TINY)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    seed_all(501)
+    r = train_step_ref(model, opt, s, a, T(g["tg_x0"]), s.get_timesteps_epoch(0, 1), s.rng, do_update=False)
+    assert np.array_equal(r["x_in"].numpy(), g["tg_xin"])
+    assert abs(float(r["loss"]) - float(g["tg_loss"])) < 1e-5 * max(1.0, float(g["tg_loss"]))
+    # do_update=False returns before backward: take the gradients here
+    x_in, t = r["x_in"], r["t"]
+    model.zero_grad()
+    pred = model(x_in, t).sample
+    w = s.get_weight_timesteps(r["timeindex"], a.loss_weight_power_base)
+    loss = (w[:, None, None, None] * ((x_in + pred) - r["shift"] - T(g["tg_x0"])) ** 2).mean()
+    loss.backward()
+    grads = {k: p.grad for k, p in zip(model.keys, model.plist)}
+    rms = float(torch.cat([v.reshape(-1) for v in grads.values()]).pow(2).mean().sqrt())
+    for k in g.files:
+        if k.startswith("tg_g::"):
+            want = g[k]
+            assert np.allclose(grads[k.split("::")[1]].numpy(), want, rtol=2e-3, atol=2e-2 * rms), k
+    norm = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
+    assert abs(norm - float(g["tg_norm"])) < 1e-4 * float(g["tg_norm"])

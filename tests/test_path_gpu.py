@@ -267,3 +267,62 @@ def test_sampler_one_graph_per_step_equals_the_host_driven_loop(dep, mode, sel, 
         outs.append(x0.cpu().numpy().copy())
     rel = np.linalg.norm(outs[0] - outs[1]) / (np.linalg.norm(outs[0]) + 1e-12)
     assert rel < 1e-3, rel
+
+
+# --------------------------------------------------------------------------------- round-2 fixtures
+@pytest.mark.parametrize("dt", [0, 1])
+def test_train_step_gradient_tensors_vs_reference(golden, dt):
+    """All 62 gradient tensors of one real reference `_run_batch` (captured before clipping) against the HIP step's
+    flat gradient buffer, and the clipping norm (trainer_masked_mean_shift.py:161-164)."""
+    g = golden("train_grads")
+    a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=10, shift_type="noise_with_perturbation", loss_weight_use=True,
+                  batch_size=4)
+    tr, model = _make_trainer("ms", a, dt)
+    seed_all(501)
+    loss = tr._run_batch(0, (T(g["tg_x0"]), None, None), 0, 1, 0, None, None)
+    assert np.array_equal(tr.step.x_in.cpu().numpy(), g["tg_xin"])
+    want_loss = float(g["tg_loss"])
+    assert abs(loss - want_loss) < (2e-5 if dt == 0 else 3e-2) * max(1.0, want_loss)
+    grads = model.store.grad_dict()
+    want = {k.split("::")[1]: g[k] for k in g.files if k.startswith("tg_g::")}
+    assert set(want) == set(grads) and len(want) == 62
+    a_ = np.concatenate([grads[k].numpy().reshape(-1) for k in want])
+    b_ = np.concatenate([want[k].reshape(-1) for k in want])
+    rel = np.linalg.norm(a_ - b_) / np.linalg.norm(b_)
+    assert rel < (2e-4 if dt == 0 else 6e-2), rel
+    if dt == 0:
+        rms = float(np.sqrt((b_ ** 2).mean()))
+        for k in want:
+            assert np.allclose(grads[k].numpy(), want[k], rtol=3e-3, atol=3e-2 * rms), k
+        norm = float(np.sqrt((a_.astype(np.float64) ** 2).sum()))
+        assert abs(norm - float(g["tg_norm"])) < 2e-4 * float(g["tg_norm"])
+        assert abs(tr.optimizer.grad_norm() - float(g["tg_norm"])) < 2e-4 * float(g["tg_norm"])       # what the clip used
+
+
+def test_sampler_trajectories_10_and_50_steps_vs_reference(golden):
+    import mdm
+    from oracle.unet_ref import random_params
+    g = golden("sampler_long")
+    model = mdm.UNet(TINY, N=2, H=16, W=16, dtype=0, params=random_params(TINY)).eval()
+    for i in range(int(g["long_n"])):
+        dep, mode, sel, ch, kind, st, Tn = [str(v) for v in g[f"long{i}_cfg"]]
+        Tn = int(Tn)
+        a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=Tn, select_degrade_pixel=sel, degrade_channel=ch,
+                      shift_type=st, sampling_mask_dependency=dep, momentum_adaptive=mode, sample_num=2,
+                      sample_latent_shape="normal", noise_mean=0.1)
+        s = mdm.Scheduler(a)
+        s.update_ddpm_num_steps(Tn)
+        ts = s.get_timesteps_epoch(0, 1)
+        assert ts == list(g[f"long{i}_ts"])
+        seed_all(600 + i)
+        x0, hist = mdm.Sampler(None, a, s, [None] * 3).sample(model, ts)
+        ref = g[f"long{i}_hist"]
+        h = np.stack([v.numpy() for v in hist])
+        h = h if Tn == 10 else h[:, ::10]
+        assert np.array_equal(h[1], ref[1]) and np.array_equal(h[6], ref[6]), i          # shifts and masks: bit-exact
+        for j in range(11):
+            sc = max(1.0, float(np.abs(ref[j]).max()))
+            assert np.linalg.norm(h[j] - ref[j]) <= 1e-3 * max(np.linalg.norm(ref[j]), 1e-6) + 1e-7, (i, j)
+            assert np.abs(h[j] - ref[j]).max() < 2e-3 * sc, (i, j)
+        rel = np.linalg.norm(x0.cpu().numpy() - g[f"long{i}_x0"]) / np.linalg.norm(g[f"long{i}_x0"])
+        assert rel < 1e-3, (i, Tn, rel)                                                   # north_star: within 1e-3 rel-L2

@@ -143,3 +143,33 @@ def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, t
     med = sorted(float(w.norm()) for w in want.values())[len(want) // 2]
     worst = max((_rel(grads[k], want[k]), k) for k in want if float(want[k].norm()) > 1e-2 * med)
     assert worst[0] < 2 * tol_g, worst
+
+
+@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
+def test_preset_width_slice_vs_reference(golden, dt, tol_y, tol_g):
+    """A one-level net at the preset's width (hid 256: res blocks 256->256 and 512->256, attention d = 256, 8x8 maps):
+    forward, input gradient, per-tensor gradient norms and a stored subset of gradients of the REFERENCE itself."""
+    from golden.make_golden import SLICE
+    from mdm import ops
+    from mdm import unet as U
+    from oracle.unet_ref import random_params
+    g = golden("blocks")
+    x, t, gy = (torch.from_numpy(g[k]) for k in ("slice_x", "slice_t", "slice_gy"))
+    net = U.UNet(SLICE, N=2, H=8, W=8, dtype=dt, params=random_params(SLICE, 9))
+    y = net(x, t).sample
+    net.zero_grad()
+    ops.nchw_to_nhwc(dt, gy.to(net.device), net.y_out.grad, 2, 3, 8, 8, net.cout_p)
+    net.run_backward()
+    torch.cuda.synchronize()
+    assert _rel(y, g["slice_y"]) < tol_y
+    grads = net.store.grad_dict()
+    keys = [str(k) for k in g["slice_keys"]]
+    assert set(keys) == set(grads)
+    norms = np.array([float(grads[k].norm()) for k in keys])
+    want = g["slice_gnorms"]
+    big = want > 1e-2 * np.median(want)
+    assert np.allclose(norms[big], want[big], rtol=5 * tol_g), np.abs(norms[big] / want[big] - 1).max()
+    for k in g.files:
+        if k.startswith("slice_g::"):
+            w = g[k]
+            assert _rel(grads[k.split("::")[1]][:w.shape[0]], w) < 2 * tol_g, k
