@@ -272,7 +272,7 @@ def test_sampler_one_graph_per_step_equals_the_host_driven_loop(dep, mode, sel, 
 # --------------------------------------------------------------------------------- round-2 fixtures
 @pytest.mark.parametrize("dt", [0, 1])
 def test_train_step_gradient_tensors_vs_reference(golden, dt):
-    """All 62 gradient tensors of one real reference `_run_batch` (captured before clipping) against the HIP step's
+    """All 128 gradient tensors of one real reference `_run_batch` (captured before clipping) against the HIP step's
     flat gradient buffer, and the clipping norm (trainer_masked_mean_shift.py:161-164)."""
     g = golden("train_grads")
     a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=10, shift_type="noise_with_perturbation", loss_weight_use=True,
@@ -285,7 +285,7 @@ def test_train_step_gradient_tensors_vs_reference(golden, dt):
     assert abs(loss - want_loss) < (2e-5 if dt == 0 else 3e-2) * max(1.0, want_loss)
     grads = model.store.grad_dict()
     want = {k.split("::")[1]: g[k] for k in g.files if k.startswith("tg_g::")}
-    assert set(want) == set(grads) and len(want) == 62
+    assert set(want) == set(grads) and len(want) == 128
     a_ = np.concatenate([grads[k].numpy().reshape(-1) for k in want])
     b_ = np.concatenate([want[k].reshape(-1) for k in want])
     rel = np.linalg.norm(a_ - b_) / np.linalg.norm(b_)

@@ -97,3 +97,49 @@ def test_preset_forward_and_all_gradients_eager_and_graph(n, dt, tol_y, tol_g):
     a = torch.cat([g_g[k].reshape(-1) for k in want])
     b = torch.cat([g_e[k].reshape(-1) for k in want])
     assert _rel(a, b) < (1e-5 if dt == 0 else 5e-3), _rel(a, b)
+
+
+# ------------------------------------------------------------------------------- full-size property runs of the other BASELINE configs
+def _args(**kw):
+    from golden.make_golden import base_args
+    return base_args(**kw)
+
+
+def test_cfg3_full_width_64x64_base_trainer_steps():
+    """BASELINE cfg3: 3x64x64, `Model('unet6',3,64,64,3)` at full width, base trainer (trainer_masked.py), N = 8 per GPU,
+    bf16, device RNG, hipGraph: the step runs, the loss is finite and falls on a repeated batch, the gradient norm is sane."""
+    import mdm
+    cfg = mdm.unet6_config(64)
+    a = _args(data_size=64, ddpm_schedule="linear", ddpm_num_steps=1000, shift_type="non_shift", batch_size=8, rng_mode="device",
+              use_ema=True, use_graph=True, seed=2)
+    model = mdm.UNet(cfg, N=8, H=64, W=64, dtype=mdm.BF16, seed=0)
+    assert model.num_parameters() == 35746307
+    opt = mdm.AdamW(model, lr=2e-4)
+    tr = mdm.BaseTrainer(a, None, None, model, mdm.EMA(model), opt, mdm.get_lr_scheduler("constant", opt, 0, 1), mdm.Accelerator())
+    a.updated_ddpm_num_steps = tr.Scheduler.update_ddpm_num_steps(1000)
+    tr.timesteps_used_epoch = tr.Scheduler.get_timesteps_epoch(0, 1)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.rand(8, 3, 64, 64, generator=g) * 2 - 1
+    losses = [tr._run_batch(0, (x0, None, None), 0, 1, 0, None, None)[0] for _ in range(12)]
+    torch.cuda.synchronize()
+    assert all(l == l and 0 < l < 10 for l in losses), losses
+    assert sum(losses[-4:]) < sum(losses[:4]), losses
+    gn = opt.grad_norm()
+    assert 1e-4 < gn < 1e3, gn
+
+
+def test_cfg5_250_step_bf16_sampler_on_the_preset():
+    """BASELINE cfg5: mean-shift setting, 250-step reverse run (base_momentum, independent masks), bf16, the 35.75 M preset,
+    device RNG, one hipGraph per reverse step: finite, bounded samples of the right shape; histories off."""
+    import mdm
+    cfg = mdm.unet6_config(32)
+    a = _args(data_size=32, ddpm_schedule="linear", ddpm_num_steps=250, shift_type="noise_with_perturbation", sample_num=8,
+              sampling_mask_dependency="independent", momentum_adaptive="base_momentum", sample_latent_shape="uniform",
+              sample_history=False, rng_mode="device", seed=4)
+    model = mdm.UNet(cfg, N=8, H=32, W=32, dtype=mdm.BF16, seed=0).eval()
+    s = mdm.Scheduler(a)
+    assert s.update_ddpm_num_steps(250) == 250
+    x0, hist = mdm.Sampler(None, a, s, [None] * 3).sample(model, s.get_timesteps_epoch(0, 1))
+    torch.cuda.synchronize()
+    assert tuple(x0.shape) == (8, 3, 32, 32) and hist == []
+    assert bool(torch.isfinite(x0).all()) and float(x0.abs().max()) < 50.0
