@@ -291,6 +291,17 @@ int mdm_sampler_update(const float* d_t, const float* d_next, float* x_t, float*
                        int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Evaluation caller (the step after the sampler; tester.py:57-223, sampler.py:487-526): the similarity matrix of
+ * generated images against data images is ONE fp32 contraction (mdm_gemm, layout 0) over unit-length rows.
+ *   mdm_normalize01  y = (x - min) / (max - min) per image [N][E], NaN -> 0       (utils/datautils.py:211-222)
+ *   mdm_unit_rows    y[r] = x[r] / max(||x[r]||, eps) over [R][D]                  (F.cosine_similarity's normalisation)
+ *   mdm_col_argmax   per column of S[M][B]: largest value and the first row holding it (score.max(dim=0), tester.py:198)
+ * ------------------------------------------------------------------------- */
+int mdm_normalize01(const float* x, float* y, int N, int E, void* stream);
+int mdm_unit_rows(const float* x, float* y, int R, int D, float eps, void* stream);
+int mdm_col_argmax(const float* S, int M, int B, float* val, int64_t* idx, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Optimizer: global-norm clip + AdamW + EMA + bf16 weight shadow in one pass over
  * flat fp32 buffers (trainer_masked_mean_shift.py:163-172, main_train_masked.py:134-141).
  *   hp (device, 8 floats): lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ema_decay

@@ -6,6 +6,7 @@ Keeps the reference's call surface: Scheduler(args), Sampler(dataset, args, Sche
 dataset_hist).sample(model, timesteps), Trainer(...).train(...), model(x, t).sample.
 """
 from . import _lib  # noqa: F401
+from . import evaluate  # noqa: F401
 from ._lib import BF16, F32  # noqa: F401
 from .dist import GradComm  # noqa: F401
 from .optim import EMA, Accelerator, AdamW, get_lr_scheduler  # noqa: F401

@@ -73,6 +73,9 @@ _PROTOS = {
     "mdm_loss_fwd_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp], i32),
     "mdm_sampler_x0": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp], i32),
     "mdm_sampler_update": ([vp, vp, vp, vp, i32, i64, vp], i32),
+    "mdm_normalize01": ([vp, vp, i32, i32, vp], i32),
+    "mdm_unit_rows": ([vp, vp, i32, i32, f32, vp], i32),
+    "mdm_col_argmax": ([vp, i32, i32, vp, vp, vp], i32),
     "mdm_rng_advance": ([vp, vp], i32),
     "mdm_sampler_step_params": ([vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp], i32),
     "mdm_sqnorm": ([vp, i64, vp, vp], i32),

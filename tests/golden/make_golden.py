@@ -416,6 +416,42 @@ def gen_train_grads(scheduler_mod, unet6, out):
         out["tg_g::" + k] = npy(v)
 
 
+def gen_evaluate(scheduler_mod, sampler_mod, out):
+    """The evaluation caller (reference tester.py / utils/datautils.py / sampler.py:46-83 'data' branch) on small inputs."""
+    import tester as tester_mod
+    from utils.datautils import normalize01
+    from oracle.evaluate_ref import data_mean_histogram
+    g = torch.Generator().manual_seed(41)
+    data = torch.rand(20, 3, 8, 8, generator=g) * 2 - 1
+    batch = torch.rand(12, 3, 8, 8, generator=g)
+    batch[3] = batch[0] + 0.02 * torch.randn(3, 8, 8, generator=g)        # near-duplicates inside the batch
+    batch[7] = batch[5] * 1.5
+    batch[9] = normalize01(data[4:5])[0] + 0.01 * torch.randn(3, 8, 8, generator=g)     # close to a data image
+    prev = torch.cat([batch[1:2] + 0.01 * torch.randn(1, 3, 8, 8, generator=g), torch.rand(3, 3, 8, 8, generator=g)])
+    const = torch.full((1, 3, 8, 8), 0.3)                                  # a constant image: normalize01 -> NaN -> 0
+    out["ev_data"] = npy(data); out["ev_batch"] = npy(batch); out["ev_prev"] = npy(prev)
+    out["ev_norm01"] = npy(normalize01(torch.cat([data[:3], const])))
+    ds = [(data[i], 0) for i in range(len(data))]
+    me = types.SimpleNamespace(cosine_similarity_th=0.9, dataset=ds, args=types.SimpleNamespace(sample_num=7, data_size=8))
+    T_ = tester_mod.Tester
+    for nm in ("cosine_similarity", "_compute_similarity"):
+        setattr(me, nm, getattr(T_, nm).__get__(me))
+    out["ev_sim"] = npy(T_._compute_similarity(me, batch, normalize01(data)))
+    uniq = T_.remove_duplicates_in_batches(me, batch)
+    out["ev_unique_in_batch"] = npy(uniq)
+    out["ev_unique_across"] = npy(T_.remove_duplicates_across_batches(me, uniq, prev))
+    out["ev_nn_idx"] = npy(T_.get_nearest_neighbor_idx(me, batch))
+    # 'data' initial latent (sampler.py:46-69) from a data-mean histogram (main_train_masked.py:60-87 restated in oracle/)
+    for area in ("image-wise", "channel-wise"):
+        a = base_args(data_size=8, sample_num=6, sample_latent_shape="data", mean_area=area)
+        s = scheduler_mod.Scheduler(a)
+        hist = data_mean_histogram(data, 6, area)
+        smp = sampler_mod.Sampler(None, a, s, hist)
+        seed_all(700)
+        out[f"ev_latent_{area}"] = npy(smp._get_latent_initial(None).contiguous())
+        out[f"ev_hist_cum_{area}"] = npy(hist[2])
+
+
 def main():
     _stub_modules()
     sys.path.insert(0, REF)
@@ -433,6 +469,7 @@ def main():
         "blocks": lambda o: gen_blocks(unet6, o),
         "sampler_long": lambda o: gen_sampler_long(scheduler_mod, sampler_mod, unet6, o),
         "train_grads": lambda o: gen_train_grads(scheduler_mod, unet6, o),
+        "evaluate": lambda o: gen_evaluate(scheduler_mod, sampler_mod, o),
     }
     only = sys.argv[1:]
     for name, fn in jobs.items():

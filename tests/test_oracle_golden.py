@@ -314,3 +314,39 @@ def test_train_step_gradient_tensors(golden):
             assert np.allclose(grads[k.split("::")[1]].numpy(), want, rtol=2e-3, atol=2e-2 * rms), k
     norm = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
     assert abs(norm - float(g["tg_norm"])) < 1e-4 * float(g["tg_norm"])
+
+
+def test_evaluation_caller_pieces(golden):
+    """oracle/evaluate_ref.py against the reference's own Tester methods / normalize01 (tester.py:140-201)."""
+    from oracle import evaluate_ref as E
+    g = golden("evaluate")
+    data, batch, prev = T(g["ev_data"]), T(g["ev_batch"]), T(g["ev_prev"])
+    const = torch.full((1, 3, 8, 8), 0.3)
+    assert np.array_equal(E.normalize01(torch.cat([data[:3], const])).numpy(), g["ev_norm01"])
+    assert np.allclose(E.compute_similarity(batch, E.normalize01(data)).numpy(), g["ev_sim"], rtol=0, atol=1e-6)
+    uniq = E.remove_duplicates_in_batches(batch)
+    assert np.array_equal(uniq.numpy(), g["ev_unique_in_batch"]) and uniq.shape[0] < batch.shape[0]
+    assert np.array_equal(E.remove_duplicates_across_batches(uniq, prev).numpy(), g["ev_unique_across"])
+    assert np.array_equal(E.get_nearest_neighbor_idx(batch, data).numpy(), g["ev_nn_idx"])
+
+
+@pytest.mark.parametrize("area", ["image-wise", "channel-wise"])
+def test_initial_latent_from_the_data_mean_histogram(golden, area):
+    """`sample_latent_shape='data'` (sampler.py:46-69): oracle AND product host code against the reference's draw."""
+    from oracle import evaluate_ref as E
+    import mdm
+    from mdm import evaluate as ME
+    g = golden("evaluate")
+    data = T(g["ev_data"])
+    a = base_args(data_size=8, sample_num=6, sample_latent_shape="data", mean_area=area)
+    hist = E.data_mean_histogram(data, 6, area)
+    assert np.allclose(hist[2].numpy(), g[f"ev_hist_cum_{area}"])
+    seed_all(700)
+    got = SamplerRef(None, a, S.SchedulerRef(a), hist)._get_latent_initial(None)
+    assert np.array_equal(got.contiguous().numpy(), g[f"ev_latent_{area}"])
+    # the product's host code: same histogram (main_train_masked.py:60-87) and the same draw
+    h2 = ME.data_mean_histogram(data, a)
+    assert tuple(h2[0]) == tuple(hist[0]) and torch.equal(h2[2], hist[2]) and all(torch.equal(x, y) for x, y in zip(h2[1], hist[1]))
+    seed_all(700)
+    got2 = mdm.Sampler(None, a, mdm.Scheduler(a), h2)._get_latent_initial(None)
+    assert np.array_equal(got2.contiguous().numpy(), g[f"ev_latent_{area}"])
