@@ -1907,13 +1907,16 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d, int
 // them as ONE flat grid: the chip is filled by the group, not by each layer on its own, so a layer needs only as
 // many k-splits as balance asks for (fewer fp32 partial slabs: the per-layer launches wrote and re-read ~0.9 GB
 // of them per step at cfg2), and ~70 launch gaps / prologues / drain tails per step disappear.
-// items[i] = {descriptor index, item index inside it, tiles per (tap, k-range), 1 = 128x128 tile / 0 = 64x64}.
+// items[i] = {descriptor index, item index inside it, tiles per (tap, k-range), tile: 2 = 256x128, 1 = 128x128, 0 = 64x64}.
+// (256 output channels x 128 input channels per workgroup feed 48 KB of operands per 64-pixel slab for twice the MFMA
+// work of the 128x128 tile's 32 KB: the loop is bound by the bytes a CU takes in, so the wider tile runs ~1.3x faster.)
 __global__ __launch_bounds__(512) void wgrad_group_kernel(const mdm_gemm_desc* descs, const int4* items, int n_items) {
     // grid == n_items: one item per workgroup; a smaller grid walks the (longest-first) list with stride gridDim.x
     for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
         const int4 it = items[i];
         const mdm_gemm_desc d = descs[it.x];
-        if (it.w) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
+        if (it.w == 2) wgrad_lin_body<256, 128, 3, 8>(d, it.y, it.z);
+        else if (it.w == 1) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
         else wgrad_lin_body<64, 64, 4, 8>(d, it.y, it.z);
         __syncthreads();            // the next item refills the LDS ring
     }
@@ -2517,12 +2520,15 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         const mdm_gemm_desc& d = r.d;
         const int BK = 64, sk = d.splitk < 1 ? 1 : d.splitk;
         const int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
-        const int n_local = (int)(r.tiles * r.zouter * sk);
+        // tile: 256 x 128 where the filter has >= 256 output channels (a multiple of 256) and the reduction is long
+        const int tile_kind = !r.big ? 0 : (d.M % 256 == 0 && d.N >= 128 ? 2 : 1);
+        const int tiles_i = tile_kind == 2 ? (d.M / 256) * cdiv(d.N, 128) : (int)r.tiles;
+        const int n_local = tiles_i * r.zouter * sk;
         for (int it = 0; it < n_local; ++it) {
-            const int ks = it / (int)(r.tiles * r.zouter);
+            const int ks = it / (tiles_i * r.zouter);
             int len = d.K - ks * chunk;
             if (len > chunk) len = chunk;
-            items.push_back(GroupItem{i, it, (int)r.tiles, r.big ? 1 : 0, (len / BK) * (r.big ? 4 : 1) + 2});
+            items.push_back(GroupItem{i, it, tiles_i, tile_kind, (len / BK) * (tile_kind == 2 ? 6 : tile_kind == 1 ? 4 : 1) + 2});
         }
         if (sk > 1) {
             const long long total4 = (long long)((int64_t)r.zouter * d.M * d.N / 4);
@@ -2555,7 +2561,7 @@ extern "C" int mdm_wgrad_group_launch(void* handle, void* stream) {
     MDM_REQUIRE(handle, "wgrad_group_launch: null handle");
     const WgradGroup* g = reinterpret_cast<const WgradGroup*>(handle);
     hipStream_t s = pick_stream(stream);
-    constexpr int bytes = 3 * (128 + 128) * 64 * 2;        // the larger of the two rings (64x64: 4 stages of 16 KiB)
+    constexpr int bytes = 3 * (256 + 128) * 64 * 2;        // the largest of the three rings (256x128: 3 stages of 48 KiB)
     static bool configured = false;
     if (!configured) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
