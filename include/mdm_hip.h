@@ -198,6 +198,14 @@ int mdm_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int N, int L, 
 int mdm_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                  int N, int L, int C, float scale, void* stream);
 
+/* The same attention with MANY SMALL heads on separate q, k, v, o tensors [N][L][C], head h = channels [h D, (h+1) D),
+ * D = C / heads in {8, 16, 32}, any L, bf16 or fp32: diffusers' attention blocks inside UNet2DModel (attention_head_dim = 8;
+ * reference utils/model.py:24-32 builds them).  lse / delta are [N][heads][L] fp32.  dq, dk, dv are written completely. */
+int mdm_attn_mh_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int N, int L, int C,
+                    int heads, float scale, void* stream);
+int mdm_attn_mh_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                    float* delta, void* dq, void* dk, void* dv, int N, int L, int C, int heads, float scale, void* stream);
+
 /* row softmax of S[rows][L] in place (unet6.py:320-322), and its backward
  * dS = P * (dP - sum_j dP*P) written over dP. */
 int mdm_softmax_fwd(int dtype, void* S, int rows, int L, void* stream);
@@ -205,6 +213,9 @@ int mdm_softmax_bwd(int dtype, const void* P, void* dP, int rows, int L, void* s
 
 /* y[N][dim] = [sin(t*f) | cos(t*f)], f_i = exp(-i*ln(1e4)/(dim/2-1))  (unet6.py:18-34); fp32 */
 int mdm_timestep_embedding(const float* t, int N, int dim, float* y, void* stream);
+/* general form: flip_sin_to_cos puts the cosines first, the exponent is -i ln(1e4) / (dim/2 - freq_shift)
+ * (diffusers `Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0)` as UNet2DModel builds it; (0, 1) = the call above) */
+int mdm_timestep_embedding2(const float* t, int N, int dim, int flip_sin_to_cos, float freq_shift, float* y, void* stream);
 /* fp32 SiLU on small [n] vectors (unet6.py:397, 359) and its backward (dx = dy * silu'(x), acc adds) */
 int mdm_silu_fwd(const float* x, float* y, int64_t n, void* stream);
 int mdm_silu_bwd(const float* x, const float* dy, float* dx, int acc, int64_t n, void* stream);

@@ -354,6 +354,135 @@ static int attn_dispatch(int which, int C, const bf16_t* qkv, bf16_t* o, const b
     return -1;
 }
 
+
+// ------------------------------------------------------------------------------------------------ many small heads
+// diffusers' attention blocks (UNet2DModel: attention_head_dim = 8 -> C / 8 heads of width 8) on separate q, k, v, o
+// tensors [N][L][C], head h = channels [h D, (h + 1) D).  A width-8 head wastes 3/4 of a 16x16x32 MFMA step and L is
+// small (<= 256) where these blocks sit, so this is a VALU kernel: one workgroup per (image, head, 256-query block), a
+// thread per query (forward, dQ) or per key (dK / dV), the other side staged through LDS in chunks of 256 rows, online
+// softmax in the forward, P recomputed from the saved log-sum-exp in the backward.  Any L, D in {8, 16, 32}.
+template <typename T, int D>
+__device__ __forceinline__ void ld_row(const T* p, float (&r)[D]) {
+#pragma unroll
+    for (int e = 0; e < D; e += Elem<T>::VEC == 8 ? 8 : 4) {
+        if (Elem<T>::VEC == 8) { float8 v = load8(p + e); r[e] = v.lo.x; r[e + 1] = v.lo.y; r[e + 2] = v.lo.z; r[e + 3] = v.lo.w; r[e + 4] = v.hi.x; r[e + 5] = v.hi.y; r[e + 6] = v.hi.z; r[e + 7] = v.hi.w; }
+        else { float4 v = load4(p + e); r[e] = v.x; r[e + 1] = v.y; r[e + 2] = v.z; r[e + 3] = v.w; }
+    }
+}
+template <typename T, int D>
+__device__ __forceinline__ void st_row(T* p, const float (&r)[D]) {
+#pragma unroll
+    for (int e = 0; e < D; e += 4) store4(p + e, make_float4(r[e], r[e + 1], r[e + 2], r[e + 3]));
+}
+
+// which: 0 forward (o, lse), 1 dQ (+ delta), 2 dK and dV
+template <typename T, int D, int WHICH>
+__global__ __launch_bounds__(256) void attn_mh_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                      T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ lse,
+                                                      float* __restrict__ delta, T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv,
+                                                      int L, int C, int H, float scale) {
+    __shared__ float sa[256 * D], sb[256 * D], sl[256], sd[256];
+    const int t = threadIdx.x, nh = blockIdx.y, n = nh / H, h = nh - n * H;
+    const int row = blockIdx.x * 256 + t;
+    const bool ok = row < L;
+    const int64_t base = (int64_t)n * L * C + h * D;          // + row * C
+    const int64_t sbase = ((int64_t)n * H + h) * L;           // lse / delta: [N][H][L]
+    const int64_t ro = base + (int64_t)(ok ? row : 0) * C;
+    float a[D], g[D], acc0[D], acc1[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) { a[e] = 0.f; g[e] = 0.f; acc0[e] = 0.f; acc1[e] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f, ls = 0.f, dl = 0.f;
+    if (WHICH == 0) ld_row<T, D>(q + ro, a);
+    if (WHICH == 1) {
+        float ov[D];
+        ld_row<T, D>(q + ro, a); ld_row<T, D>(d_o + ro, g); ld_row<T, D>(o + ro, ov);
+#pragma unroll
+        for (int e = 0; e < D; ++e) dl = fmaf(g[e], ov[e], dl);
+        ls = lse[sbase + (ok ? row : 0)];
+        if (ok) delta[sbase + row] = dl;
+    }
+    if (WHICH == 2) { ld_row<T, D>(k + ro, a); ld_row<T, D>(v + ro, g); }
+    for (int c0 = 0; c0 < L; c0 += 256) {
+        const int cn = min(256, L - c0);
+        __syncthreads();
+        if (t < cn) {
+            const int64_t co = base + (int64_t)(c0 + t) * C;
+            float r0[D], r1[D];
+            if (WHICH == 2) { ld_row<T, D>(q + co, r0); ld_row<T, D>(d_o + co, r1); sl[t] = lse[sbase + c0 + t]; sd[t] = delta[sbase + c0 + t]; }
+            else { ld_row<T, D>(k + co, r0); ld_row<T, D>(v + co, r1); }
+#pragma unroll
+            for (int e = 0; e < D; ++e) { sa[t * D + e] = r0[e]; sb[t * D + e] = r1[e]; }
+        }
+        __syncthreads();
+        for (int j = 0; j < cn; ++j) {
+            const float* pa = sa + j * D;       // forward / dQ: key j and its value; dK/dV: query j and its dO
+            const float* pb = sb + j * D;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < D; ++e) s = fmaf(a[e], pa[e], s);
+            s *= scale;
+            if (WHICH == 0) {
+                const float mn = fmaxf(m, s), al = __expf(m - mn), p = __expf(s - mn);
+                lsum = lsum * al + p; m = mn;
+#pragma unroll
+                for (int e = 0; e < D; ++e) acc0[e] = fmaf(p, pb[e], acc0[e] * al);
+            } else if (WHICH == 1) {
+                const float p = __expf(s - ls);
+                float dp = 0.f;
+#pragma unroll
+                for (int e = 0; e < D; ++e) dp = fmaf(g[e], pb[e], dp);
+                const float ds = p * (dp - dl) * scale;
+#pragma unroll
+                for (int e = 0; e < D; ++e) acc0[e] = fmaf(ds, pa[e], acc0[e]);
+            } else {
+                const float p = __expf(s - sl[j]);      // a = this key, pa = query j: s is the same score
+                float dp = 0.f;
+#pragma unroll
+                for (int e = 0; e < D; ++e) dp = fmaf(g[e], pb[e], dp);      // v . dO_j
+                const float ds = p * (dp - sd[j]) * scale;
+#pragma unroll
+                for (int e = 0; e < D; ++e) { acc0[e] = fmaf(ds, pa[e], acc0[e]); acc1[e] = fmaf(p, pb[e], acc1[e]); }
+            }
+        }
+    }
+    if (!ok) return;
+    if (WHICH == 0) {
+        const float inv = 1.f / lsum;
+#pragma unroll
+        for (int e = 0; e < D; ++e) acc0[e] *= inv;
+        st_row<T, D>(o + ro, acc0);
+        lse[sbase + row] = m + __logf(lsum);
+    } else if (WHICH == 1) {
+        st_row<T, D>(dq + ro, acc0);
+    } else {
+        st_row<T, D>(dk + ro, acc0);
+        st_row<T, D>(dv + ro, acc1);
+    }
+}
+
+template <typename T, int D>
+static int attn_mh_launch(int which, const void* q, const void* k, const void* v, void* o, const void* d_o, float* lse, float* delta,
+                          void* dq, void* dk, void* dv, int N, int L, int C, int H, float scale, hipStream_t s) {
+    dim3 grid((unsigned)cdiv(L, 256), (unsigned)(N * H));
+#define MDM_MH(W) hipLaunchKernelGGL((attn_mh_kernel<T, D, W>), grid, dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, (T*)o, \
+                                     (const T*)d_o, lse, delta, (T*)dq, (T*)dk, (T*)dv, L, C, H, scale)
+    if (which == 0) MDM_MH(0);
+    else { MDM_MH(1); MDM_MH(2); }
+#undef MDM_MH
+    return launch_status("attention (multi-head)");
+}
+template <typename T>
+static int attn_mh_dispatch(int which, int D, const void* q, const void* k, const void* v, void* o, const void* d_o, float* lse,
+                            float* delta, void* dq, void* dk, void* dv, int N, int L, int C, int H, float scale, hipStream_t s) {
+    switch (D) {
+        case 8: return attn_mh_launch<T, 8>(which, q, k, v, o, d_o, lse, delta, dq, dk, dv, N, L, C, H, scale, s);
+        case 16: return attn_mh_launch<T, 16>(which, q, k, v, o, d_o, lse, delta, dq, dk, dv, N, L, C, H, scale, s);
+        case 32: return attn_mh_launch<T, 32>(which, q, k, v, o, d_o, lse, delta, dq, dk, dv, N, L, C, H, scale, s);
+    }
+    set_error("attention (multi-head): head width %d is not one of 8, 16, 32", D);
+    return -1;
+}
+
 }  // namespace mdm
 using namespace mdm;
 
@@ -371,4 +500,23 @@ extern "C" int mdm_attn_bwd(int dtype, const void* qkv, const void* o, const voi
     MDM_REQUIRE(qkv && o && d_o && lse && delta && dqkv && N > 0, "attn_bwd: bad arguments");
     return attn_dispatch(1, C, (const bf16_t*)qkv, (bf16_t*)const_cast<void*>(o), (const bf16_t*)d_o, const_cast<float*>(lse), delta,
                          (bf16_t*)dqkv, N, L, scale, pick_stream(stream));
+}
+
+extern "C" int mdm_attn_mh_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int N, int L, int C,
+                               int heads, float scale, void* stream) {
+    MDM_REQUIRE(q && k && v && o && lse && N > 0 && L > 0 && heads > 0 && C % heads == 0, "attn_mh_fwd: bad arguments");
+    hipStream_t s = pick_stream(stream);
+    if (dtype == MDM_BF16) return attn_mh_dispatch<bf16_t>(0, C / heads, q, k, v, o, nullptr, lse, nullptr, nullptr, nullptr, nullptr, N, L, C, heads, scale, s);
+    if (dtype == MDM_F32) return attn_mh_dispatch<float>(0, C / heads, q, k, v, o, nullptr, lse, nullptr, nullptr, nullptr, nullptr, N, L, C, heads, scale, s);
+    set_error("attn_mh_fwd: bad dtype %d", dtype);
+    return -1;
+}
+extern "C" int mdm_attn_mh_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                               float* delta, void* dq, void* dk, void* dv, int N, int L, int C, int heads, float scale, void* stream) {
+    MDM_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv && N > 0 && L > 0 && heads > 0 && C % heads == 0, "attn_mh_bwd: bad arguments");
+    hipStream_t s = pick_stream(stream);
+    if (dtype == MDM_BF16) return attn_mh_dispatch<bf16_t>(1, C / heads, q, k, v, const_cast<void*>(o), d_o, const_cast<float*>(lse), delta, dq, dk, dv, N, L, C, heads, scale, s);
+    if (dtype == MDM_F32) return attn_mh_dispatch<float>(1, C / heads, q, k, v, const_cast<void*>(o), d_o, const_cast<float*>(lse), delta, dq, dk, dv, N, L, C, heads, scale, s);
+    set_error("attn_mh_bwd: bad dtype %d", dtype);
+    return -1;
 }

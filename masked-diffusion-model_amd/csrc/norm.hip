@@ -701,15 +701,17 @@ __global__ void add_kernel(T* dst, const T* x, const T* y, int64_t nvec) {      
     }
 }
 
-__global__ void temb_kernel(const float* t, int N, int dim, float* y) {
+// flip = 0, shift = 1: unet6.py:18-34 ([sin | cos], exponent / (half - 1)); flip = 1, shift = 0: diffusers' `Timesteps(
+// flip_sin_to_cos=True, downscale_freq_shift=0)` as UNet2DModel builds it ([cos | sin], exponent / half)
+__global__ void temb_kernel(const float* t, int N, int dim, int flip, float shift, float* y) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int half = dim / 2;
     if (i >= N * half) return;
     int n = i / half, j = i - n * half;
-    float f = expf(-(float)j * (logf(10000.f) / (float)(half - 1)));
+    float f = expf(-(float)j * (logf(10000.f) / ((float)half - shift)));
     float a = t[n] * f;
-    y[n * dim + j] = sinf(a);
-    y[n * dim + half + j] = cosf(a);
+    y[n * dim + (flip ? half : 0) + j] = sinf(a);
+    y[n * dim + (flip ? 0 : half) + j] = cosf(a);
     if ((dim & 1) && j == 0) y[n * dim + dim - 1] = 0.f;
 }
 __global__ void silu_fwd_kernel(const float* x, float* y, int64_t n) {
@@ -855,7 +857,13 @@ extern "C" int mdm_softmax_bwd(int dtype, const void* P, void* dP, int rows, int
 
 extern "C" int mdm_timestep_embedding(const float* t, int N, int dim, float* y, void* stream) {
     MDM_REQUIRE(N > 0 && dim >= 4, "timestep_embedding: bad shape");
-    hipLaunchKernelGGL(temb_kernel, dim3(cdiv(N * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, N, dim, y);
+    hipLaunchKernelGGL(temb_kernel, dim3(cdiv(N * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, N, dim, 0, 1.f, y);
+    return launch_status("timestep_embedding");
+}
+extern "C" int mdm_timestep_embedding2(const float* t, int N, int dim, int flip_sin_to_cos, float freq_shift, float* y, void* stream) {
+    MDM_REQUIRE(N > 0 && dim >= 4, "timestep_embedding: bad shape");
+    hipLaunchKernelGGL(temb_kernel, dim3(cdiv(N * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, N, dim, flip_sin_to_cos,
+                       freq_shift, y);
     return launch_status("timestep_embedding");
 }
 extern "C" int mdm_silu_fwd(const float* x, float* y, int64_t n, void* stream) {

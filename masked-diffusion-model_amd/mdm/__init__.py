@@ -14,3 +14,4 @@ from .sampler import Sampler  # noqa: F401
 from .scheduler import Scheduler  # noqa: F401
 from .trainer import BaseTrainer, Trainer  # noqa: F401
 from .unet import UNet, unet6_config  # noqa: F401
+from .unet2d import UNet2D, my_model_config  # noqa: F401

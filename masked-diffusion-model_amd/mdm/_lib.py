@@ -55,9 +55,12 @@ _PROTOS = {
     "mdm_attn_supported": ([i32, i32, i32], i32),
     "mdm_attn_fwd": ([i32, vp, vp, vp, i32, i32, i32, f32, vp], i32),
     "mdm_attn_bwd": ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),
+    "mdm_attn_mh_fwd": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp], i32),
+    "mdm_attn_mh_bwd": ([i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp], i32),
     "mdm_softmax_fwd": ([i32, vp, i32, i32, vp], i32),
     "mdm_softmax_bwd": ([i32, vp, vp, i32, i32, vp], i32),
     "mdm_timestep_embedding": ([vp, i32, i32, vp, vp], i32),
+    "mdm_timestep_embedding2": ([vp, i32, i32, i32, f32, vp, vp], i32),
     "mdm_silu_fwd": ([vp, vp, i64, vp], i32),
     "mdm_silu_bwd": ([vp, vp, vp, i32, i64, vp], i32),
     "mdm_colsum": ([i32, vp, i32, i32, i32, vp, i32, i32, vp, vp], i32),

@@ -204,8 +204,20 @@ def softmax_bwd(dt, P, dP, rows, L):
     call("mdm_softmax_bwd", dt, ptr(P), ptr(dP), rows, L, stream())
 
 
-def timestep_embedding(t, N, dim, y):
-    call("mdm_timestep_embedding", ptr(t), N, dim, ptr(y), stream())
+def timestep_embedding(t, N, dim, y, variant=None):
+    if variant is None:
+        call("mdm_timestep_embedding", ptr(t), N, dim, ptr(y), stream())
+    else:
+        call("mdm_timestep_embedding2", ptr(t), N, dim, int(bool(variant[0])), float(variant[1]), ptr(y), stream())
+
+
+def attn_mh_fwd(dt, q, k, v, o, lse, N, L, C, heads, scale):
+    call("mdm_attn_mh_fwd", dt, ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), N, L, C, heads, float(scale), stream())
+
+
+def attn_mh_bwd(dt, q, k, v, o, do, lse, delta, dq, dk, dv, N, L, C, heads, scale):
+    call("mdm_attn_mh_bwd", dt, ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+         N, L, C, heads, float(scale), stream())
 
 
 def silu_fwd(x, y, n):

@@ -85,7 +85,7 @@ class ParamStore:
             self.PbT = torch.zeros(self.size, device=device, dtype=torch.bfloat16)
             rows = []
             for e in self.entries.values():
-                if e.kind != "conv":
+                if e.kind not in ("conv", "convlin"):
                     continue
                 taps, co, ci = e.ishape
                 for tp in range(taps):
@@ -134,6 +134,11 @@ class ParamStore:
             out = torch.zeros(e.ishape, dtype=torch.float32)
             out[:, :o, :i] = t.permute(2, 3, 0, 1).reshape(kh * kw, o, i)
             return out
+        if e.kind == "convlin":            # an nn.Linear [out, in] run as a 1x1 convolution
+            o, i = e.rshape
+            out = torch.zeros(e.ishape, dtype=torch.float32)
+            out[0, :o, :i] = t
+            return out
         if e.kind == "vecpad":
             out = torch.zeros(e.ishape, dtype=torch.float32)
             out[:e.rshape[0]] = t
@@ -146,6 +151,9 @@ class ParamStore:
         if e.kind == "conv":
             o, i, kh, kw = e.rshape
             return t[:, :o, :i].reshape(kh, kw, o, i).permute(2, 3, 0, 1).contiguous()
+        if e.kind == "convlin":
+            o, i = e.rshape
+            return t[0, :o, :i].clone()
         if e.kind == "vecpad":
             return t[:e.rshape[0]].clone()
         return t.reshape(e.rshape).clone()
@@ -189,7 +197,7 @@ class _Conv:
     def declare(self, st):
         g = self.g
         rs = self.rshape
-        st.declare(self.name + ".weight", "conv", rs, (g.taps, g.Cout, g.Cin))
+        st.declare(self.name + ".weight", "conv" if len(rs) == 4 else "convlin", rs, (g.taps, g.Cout, g.Cin))
         st.declare(self.name + ".bias", "vecpad", (rs[0],), (g.Cout,))
 
     def fwd(self):
@@ -272,8 +280,8 @@ class _Conv:
 
 
 class _Norm:
-    def __init__(self, net, name, src0, src1, out, silu):
-        self.net, self.name, self.src0, self.src1, self.out, self.silu = net, name, src0, src1, out, silu
+    def __init__(self, net, name, src0, src1, out, silu, eps=1e-6):
+        self.net, self.name, self.src0, self.src1, self.out, self.silu, self.eps = net, name, src0, src1, out, silu, eps
 
     def declare(self, st):
         c = self.out.C
@@ -291,10 +299,11 @@ class _Norm:
         if (n.dt == BF16 and _lib._recording is not None and s1 is None and isinstance(prev, _Conv)
                 and prev.out is s0 and getattr(prev, "fwd_desc", None) is not None and ops.conv_fwd_can_fuse_gn(prev.fwd_desc)):
             ops.fuse_gn_fwd(prev.fwd_desc, dict(out=self.out.data, gamma=st.f(self.name + ".weight"), beta=st.f(self.name + ".bias"),
-                                                stats=self.stats, G=32, silu=self.silu, eps=1e-6))
+                                                stats=self.stats, G=32, silu=self.silu, eps=self.eps))
             return
         ops.groupnorm_fwd(n.dt, s0.data, s0.C, s1.data if s1 else None, s1.C if s1 else 0, s0.N, s0.P,
-                          st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, self.out.data, self.stats, n.gn_ws)
+                          st.f(self.name + ".weight"), st.f(self.name + ".bias"), self.silu, self.out.data, self.stats, n.gn_ws,
+                          eps=self.eps)
 
     def bwd(self):
         n, st = self.net, self.net.store
@@ -365,24 +374,26 @@ class _Temb:
     """Sinusoidal embedding -> 2-layer MLP -> SiLU -> all 22 per-block projections in one
     contraction (unet6.py:18-34, 395-399, 350, 359).  fp32 throughout (rows = batch only)."""
 
-    def __init__(self, net, hid, temb, fc_total):
+    def __init__(self, net, hid, temb, fc_total, names=("embed.0", "embed.2"), variant=None):
         self.net, self.hid, self.temb, self.fc_total = net, hid, temb, fc_total
+        self.l1, self.l2 = names
+        self.variant = variant          # None: unet6.py:18-34; (flip_sin_to_cos, freq_shift): diffusers' Timesteps
 
     def declare(self, st):
-        st.declare("embed.0.weight", "lin", (self.temb, self.hid), (self.temb, self.hid))
-        st.declare("embed.0.bias", "vec", (self.temb,), (self.temb,))
-        st.declare("embed.2.weight", "lin", (self.temb, self.temb), (self.temb, self.temb))
-        st.declare("embed.2.bias", "vec", (self.temb,), (self.temb,))
+        st.declare(self.l1 + ".weight", "lin", (self.temb, self.hid), (self.temb, self.hid))
+        st.declare(self.l1 + ".bias", "vec", (self.temb,), (self.temb,))
+        st.declare(self.l2 + ".weight", "lin", (self.temb, self.temb), (self.temb, self.temb))
+        st.declare(self.l2 + ".bias", "vec", (self.temb,), (self.temb,))
 
     def fwd(self):
         n, st = self.net, self.net.store
         N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
         f = lambda *s: n.alloc(s, torch.float32)
         self.e, self.h1, self.a1, self.tm, self.st_ = f(N, hid), f(N, te), f(N, te), f(N, te), f(N, te)
-        ops.timestep_embedding(n.t_in, N, hid, self.e)
-        ops.matmul(F32, 0, N, te, hid, self.e, hid, st.f("embed.0.weight"), hid, self.h1, te, bias=st.f("embed.0.bias"))
+        ops.timestep_embedding(n.t_in, N, hid, self.e, self.variant)
+        ops.matmul(F32, 0, N, te, hid, self.e, hid, st.f(self.l1 + ".weight"), hid, self.h1, te, bias=st.f(self.l1 + ".bias"))
         ops.silu_fwd(self.h1, self.a1, N * te)
-        ops.matmul(F32, 0, N, te, te, self.a1, te, st.f("embed.2.weight"), te, self.tm, te, bias=st.f("embed.2.bias"))
+        ops.matmul(F32, 0, N, te, te, self.a1, te, st.f(self.l2 + ".weight"), te, self.tm, te, bias=st.f(self.l2 + ".bias"))
         ops.silu_fwd(self.tm, self.st_, N * te)
         ops.matmul(F32, 0, N, ft, te, self.st_, te, n.fc_w, te, n.T_all, ft, bias=n.fc_b)
 
@@ -396,12 +407,12 @@ class _Temb:
         ops.fill(d_st, 0.0)                                   # K = sum(Cout) ~ 5k against M = batch: split the reduction
         ops.matmul(F32, 1, N, te, ft, n.dT_all, ft, n.fc_w, te, d_st, te, splitk=max(1, min(32, ft // 128)))
         ops.silu_bwd(self.tm, d_st, d_tm, 0, N * te)
-        ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g("embed.2.weight"), te, acc=1, out_f32=1)
-        ops.colsum(F32, d_tm, 1, N, te, dbias=st.g("embed.2.bias"))
-        ops.matmul(F32, 1, N, te, te, d_tm, te, st.f("embed.2.weight"), te, d_a1, te)
+        ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g(self.l2 + ".weight"), te, acc=1, out_f32=1)
+        ops.colsum(F32, d_tm, 1, N, te, dbias=st.g(self.l2 + ".bias"))
+        ops.matmul(F32, 1, N, te, te, d_tm, te, st.f(self.l2 + ".weight"), te, d_a1, te)
         ops.silu_bwd(self.h1, d_a1, d_h1, 0, N * te)
-        ops.matmul(F32, 2, te, hid, N, d_h1, te, self.e, hid, st.g("embed.0.weight"), hid, acc=1, out_f32=1)
-        ops.colsum(F32, d_h1, 1, N, te, dbias=st.g("embed.0.bias"))
+        ops.matmul(F32, 2, te, hid, N, d_h1, te, self.e, hid, st.g(self.l1 + ".weight"), hid, acc=1, out_f32=1)
+        ops.colsum(F32, d_h1, 1, N, te, dbias=st.g(self.l1 + ".bias"))
 
 
 # --------------------------------------------------------------------------- #
@@ -447,12 +458,15 @@ class UNet:
         self._materialize()
         if not shared:
             if params is None:
-                from .init import xavier_like_params
-                params = xavier_like_params(self.reference_shapes(), seed)
+                params = self._default_params(seed)
             self.load_state_dict(params)
         self.forward_plan = self._record(self._emit_fwd)
         self.backward_plan = self._record(self._emit_bwd)
         self._graph_fwd = None
+
+    def _default_params(self, seed):
+        from .init import xavier_like_params
+        return xavier_like_params(self.reference_shapes(), seed)
 
     @staticmethod
     def param_table(cfg, H=32, W=32):
