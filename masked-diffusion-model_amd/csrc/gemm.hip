@@ -2231,9 +2231,9 @@ static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of on
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW, int NSB>
+template <int BM, int NPW, int NSB, int BN = 64>
 static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filter row (3 taps) per barrier
-    constexpr int BN = 64, TG = 3;
+    constexpr int TG = 3;
     const int NPA = halo_pieces(BM, d.OH, d.OW);
     int bytes = 2 * NPA * 1024 + NSB * TG * BN * 128 + 1024;
     if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
@@ -2414,7 +2414,12 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
             rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 2>(d, s) : launch_halo<256, 6, 2>(d, s))
                  : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 2>(d, s) : npw <= 4 ? launch_halo<128, 4, 2>(d, s) : launch_halo<128, 6, 2>(d, s))
-                             : (npw <= 2 ? launch_halo<64, 2, 3>(d, s) : launch_halo<64, 3, 3>(d, s));
+                 // whole-image 64-pixel tiles (4x4 / 8x8 maps): the loop is the filter stream of ONE workgroup (64 output
+                 // channels x 9 C x 2 B at ~27 B/clk), so without a fused GroupNorm epilogue (which needs whole groups of a
+                 // 64-channel tile) 32 output channels per workgroup halve it and double the workgroups
+                 : (!d.gnb_x && !d.gnf_out && d.N % 32 == 0)
+                     ? (npw <= 2 ? launch_halo<64, 2, 3, 32>(d, s) : launch_halo<64, 3, 3, 32>(d, s))
+                     : (npw <= 2 ? launch_halo<64, 2, 3>(d, s) : launch_halo<64, 3, 3>(d, s));
         } else if (big) {
             rc = launch_lin2<128, 128, 3, 4, 2>(d, grid, s);
         } else if (d.N >= 128 && t_mid >= kBigMinTiles) {
