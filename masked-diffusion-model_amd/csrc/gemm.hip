@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tile_i = (int)blockIdx.x;         // (an XCD-aware remap of the tile index was measured: no gain at cfg2)
+    const int tile_i = xcd_remap((int)blockIdx.x, (int)gridDim.x);     // XCD-aware tile order: see conv_halo_kernel
     const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int sk = d.splitk < 1 ? 1 : d.splitk;
@@ -1914,6 +1914,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const mdm_gemm_desc* d
     // grid == n_items: one item per workgroup; a smaller grid walks the (longest-first) list with stride gridDim.x
     for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
         const int4 it = items[i];
+        if (it.x < 0) continue;             // padding of the per-XCD queues (uniform for the workgroup)
         const mdm_gemm_desc d = descs[it.x];
         if (it.w == 2) wgrad_lin_body<256, 128, 3, 8>(d, it.y, it.z);
         else if (it.w == 1) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
@@ -1978,7 +1979,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     char* const bring = lds + 2 * ABUF;
     char* const dummy = bring + NSB * STAGE_B;
     const int tiles_n = d.N / BN;
-    const int mt = blockIdx.x / tiles_n, n0 = (blockIdx.x - mt * tiles_n) * BN, m0 = mt * BM;
+    // XCD-aware tile order (xcd_remap): the output-channel tiles of one pixel tile read the same halo and neighbouring
+    // pixel tiles the same filter slabs -- handing each XCD a CONTIGUOUS eighth of the tile list lets them meet in ONE L2
+    // instead of eight.  No effect on time at cfg2 (the loop is bound by the CU's intake, not by L2 misses); it is there
+    // for the L2-side traffic (FETCH_SIZE), which counts every XCD's own fetch of the same line.
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int mt = bid / tiles_n, n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
     const int img = m0 / (OH * OW), y0 = (m0 / OW) % OH;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int NCS = d.Ck / 64;                       // 64-channel slabs over both sources
@@ -2545,20 +2551,48 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         }
     }
     close_table();
-    // longest items first: the short ones fill the tail of the launch
-    std::stable_sort(items.begin(), items.end(), [](const GroupItem& a, const GroupItem& b) { return a.cost > b.cost; });
+    // Order.  The items of one (layer, k-range) -- every filter tap x output tile -- read the same dY and input slabs,
+    // so they should meet in ONE XCD's L2 (each of the 8 XCDs otherwise fetches the slabs for itself: this kernel was
+    // 2.8 GB of the step's 6.3 GB of L2-side traffic).  Workgroup b runs on XCD b % 8 (observed dispatch rule, used for
+    // speed only): the table is laid out [8 queues][maxlen], workgroup b takes entry (b % 8, b / 8).  Bundles go longest
+    // first to the queue with the least work so far (short ones fill the tail); unused entries are no-ops (desc -1).
+    std::vector<std::pair<long long, std::pair<int, int>>> bundles;            // (cost of one item, [first, last) in `items`)
+    for (size_t a = 0; a < items.size();) {
+        size_t b = a;
+        const int per = items[a].tiles_x * (int)(ds[(size_t)items[a].desc].KH * ds[(size_t)items[a].desc].KW);
+        while (b < items.size() && items[b].desc == items[a].desc && items[b].item / per == items[a].item / per) ++b;
+        // (at most 12 items per bundle -- a few neighbouring taps x the output tiles: whole 18..72-item bundles balance
+        // the 32 CUs of an XCD too coarsely, measured +1 % on the step)
+        for (size_t c = a; c < b; c += 12) bundles.push_back({items[a].cost, {(int)c, (int)(c + 12 < b ? c + 12 : b)}});
+        a = b;
+    }
+    std::stable_sort(bundles.begin(), bundles.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+    std::vector<std::vector<int>> queue(8);
+    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const auto& bd : bundles) {
+        int q = 0;
+        for (int x = 1; x < 8; ++x) if (load[x] < load[q]) q = x;
+        for (int i = bd.second.first; i < bd.second.second; ++i) { queue[(size_t)q].push_back(i); load[q] += items[(size_t)i].cost; }
+    }
+    size_t maxlen = 0;
+    for (const auto& qv : queue) maxlen = qv.size() > maxlen ? qv.size() : maxlen;
+    const size_t n_slots = 8 * maxlen;
     const int64_t desc_bytes = ((int64_t)n * (int64_t)sizeof(mdm_gemm_desc) + 255) / 256 * 256;
-    const int64_t need = desc_bytes + (int64_t)items.size() * 16;
+    const int64_t need = desc_bytes + (int64_t)n_slots * 16;
     *need_bytes_out = need;
     if (!dev_buf || dev_bytes < need) { delete g; return 0; }      // size query
-    std::vector<int4> it4(items.size());
-    for (size_t i = 0; i < items.size(); ++i) it4[i] = make_int4(items[i].desc, items[i].item, items[i].tiles_x, items[i].big);
+    std::vector<int4> it4(n_slots, make_int4(-1, 0, 0, 0));
+    for (int x = 0; x < 8; ++x)
+        for (size_t w = 0; w < queue[(size_t)x].size(); ++w) {
+            const GroupItem& gi = items[(size_t)queue[(size_t)x][w]];
+            it4[w * 8 + (size_t)x] = make_int4(gi.desc, gi.item, gi.tiles_x, gi.big);      // slot of workgroup b = w * 8 + x
+        }
     hipError_t e = hipMemcpy(dev_buf, ds.data(), (size_t)n * sizeof(mdm_gemm_desc), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(dev_buf) + desc_bytes, it4.data(), it4.size() * 16, hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete g; return hip_fail(e, "wgrad_group_create: hipMemcpy"); }
     g->descs_dev = reinterpret_cast<const mdm_gemm_desc*>(dev_buf);
     g->items_dev = reinterpret_cast<const int4*>(reinterpret_cast<char*>(dev_buf) + desc_bytes);
-    g->n_items = (int)items.size();
+    g->n_items = (int)n_slots;
     *handle_out = g;
     return 0;
 }

@@ -12,7 +12,8 @@ import torch
 
 F32, BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdm_hip.so")
+# (MDM_LIB_PATH: load another BUILD of the same library -- A/B timing of two builds on one box; it selects a file, not a code path)
+LIB_PATH = os.environ.get("MDM_LIB_PATH") or os.path.join(_HERE, "libmdm_hip.so")
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
