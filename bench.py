@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--no-sampler", action="store_true")
     ap.add_argument("--sampler-steps", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the event-timed replay (kernel-count profiles: every profiled launch then belongs to a whole step)")
     ap.add_argument("--wgrad-group-mb", type=float, default=None, help=argparse.SUPPRESS)      # experiments only
     ap.add_argument("--overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1)")
@@ -271,7 +272,7 @@ def main():
     # ---- roofline of the contraction kernel family: HIP events around every launch, on the launch stream
     roofline = None
     step_hbm = None
-    if rank == 0:
+    if rank == 0 and not opt_.no_roofline:
         st = torch.cuda.current_stream().cuda_stream
         with _lib.Recording() as front:
             step._emit_device_front()

@@ -14,7 +14,7 @@ def stamps(reset=1):
     buf = (ctypes.c_ulonglong * (4096 * 32))(); assert fn(buf, reset) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 32).astype(np.float64)
     return a[a[:, 5] > 0]
-shapes = [(128, 0, 128, 32), (256, 0, 256, 16), (256, 0, 256, 8), (256, 0, 256, 4)]
+shapes = [(128, 0, 128, 32), (256, 0, 128, 32), (256, 0, 256, 16), (256, 0, 256, 8)]
 for (c0, c1, co, H) in shapes:
     g = ops.ConvGeom(N=32, IH=H, IW=H, C0=c0, C1=c1, Cout=co, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, pad_b=1, pad_r=1, ups=0)
     bf = torch.bfloat16
