@@ -220,6 +220,22 @@ int mdm_timestep_embedding2(const float* t, int N, int dim, int flip_sin_to_cos,
 int mdm_silu_fwd(const float* x, float* y, int64_t n, void* stream);
 int mdm_silu_bwd(const float* x, const float* dy, float* dx, int acc, int64_t n, void* stream);
 
+/* The linear layers of the time-embedding path (unet6.py:395-399 `embed`, unet6.py:350 the per-block projections, all in one
+ * [sum Cout][temb] matrix) and their data gradients: fp32 contractions whose row count M is the batch.  M <= 128,
+ * N % 16 == 0, K % (64 * splits) == 0 (mdm_skinny_supported); larger batches go through mdm_gemm.
+ *   fwd: y[M][N] = x[M][K] W[N][K]^T + bias; act_out (may be NULL) = silu(y).  With x == NULL the input is the sinusoidal
+ *        embedding of t[M] (dimension K, as mdm_timestep_embedding2), also stored to emb_out[M][K] when that is not NULL.
+ *   bwd: dx[M][N] = dy[M][K] W[K][N] (* silu'(pre[M][N]) when pre != NULL); with splits > 1 the reduction is cut into
+ *        `splits` ranges whose fp32 partial results go to slabs[splits][M][N] (pre and dx unused) for mdm_silu_bwd_sum.
+ *   mdm_silu_bwd_sum: dx[n] = (sum_s slabs[s][n]) * silu'(pre[n]) (pre may be NULL: plain sum). */
+int mdm_skinny_supported(int M, int N, int K, int splits);
+int mdm_skinny_linear_fwd(const float* x, int ldx, const float* t, int flip_sin_to_cos, float freq_shift, float* emb_out,
+                          const float* W, int ldw, const float* bias, int M, int N, int K, float* y, int ldy, float* act_out,
+                          void* stream);
+int mdm_skinny_linear_bwd(const float* dy, int lddy, const float* W, int ldw, int M, int N, int K, int splits, const float* pre,
+                          float* dx, float* slabs, void* stream);
+int mdm_silu_bwd_sum(const float* pre, const float* slabs, int nslab, int64_t n, float* dx, void* stream);
+
 /* column sums of dY[N][P][C] (NHWC): per_img[n*ld + c] (= or +=) sum_p, and dbias[c] += sum_{n,p}.
  * Either output may be NULL.  Backward of the bias add (unet6.py:233) and of the
  * time-embedding broadcast add (unet6.py:359). */

@@ -3,7 +3,7 @@
 // on qkv = project_in(norm(x)) stored NHWC as [N][L][3C] (q | k | v), bf16.
 //
 // The unfused path (two batched contractions + a softmax launch, S[N][L][L] materialised in HBM; five more
-// launches and dP[N][L][L] in the backward) is replaced by ONE forward kernel and TWO backward kernels that
+// launches and dP[N][L][L] in the backward) is replaced by ONE forward kernel and ONE backward launch (dQ and dK/dV workgroups side by side) that
 // never write the scores: per 64-query tile the keys are walked in tiles of 64 with an online softmax
 // (running max m, running sum l per query), the backward recomputes P from q, k and the saved
 // log-sum-exp.  QK^T, PV and the four backward products run on v_mfma_f32_16x16x32_bf16.
@@ -176,11 +176,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (and delta)
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, float scale) {
+__device__ __forceinline__ void attn_bwd_dq_body(char* lds, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                 const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                 float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, float scale) {
     constexpr int KS = D / 32, DB = D / 16;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Kt = lds;
     char* Vt = lds + 64 * 2 * D;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
@@ -245,12 +244,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
+// delta[q] = sum_d dO[q][d] O[q][d] is recomputed here for the image's L queries (4 threads per query, into LDS) rather than
+// read from the dQ workgroups: the two halves of the backward then have no dependency and run as ONE launch
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           bf16_t* __restrict__ dqkv, int L, float scale) {
+__device__ __forceinline__ void attn_bwd_dkv_body(char* lds, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                  bf16_t* __restrict__ dqkv, int L, float scale) {
     constexpr int KS = D / 32, DB = D / 16;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Qt = lds;
     char* Gt = lds + 64 * 2 * D;           // dO tile
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
@@ -270,7 +270,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int db = 0; db < DB; ++db) { dK[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const float* lse_n = lse + (int64_t)n * L;
-    const float* del_n = delta + (int64_t)n * L;
+    float* del_n = reinterpret_cast<float*>(lds + 2 * 64 * 2 * D);
+    for (int q = t >> 2; q < L; q += 64) {
+        const int part = t & 3;
+        const bf16_t* po = o + ((int64_t)n * L + q) * D + part * (D / 4);
+        const bf16_t* pg = d_o + ((int64_t)n * L + q) * D + part * (D / 4);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < D / 4; e += 8) {
+            const float8 a = load8(po + e), b = load8(pg + e);
+            sum = fmaf(a.lo.x, b.lo.x, sum); sum = fmaf(a.lo.y, b.lo.y, sum); sum = fmaf(a.lo.z, b.lo.z, sum); sum = fmaf(a.lo.w, b.lo.w, sum);
+            sum = fmaf(a.hi.x, b.hi.x, sum); sum = fmaf(a.hi.y, b.hi.y, sum); sum = fmaf(a.hi.z, b.hi.z, sum); sum = fmaf(a.hi.w, b.hi.w, sum);
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if (part == 0) del_n[q] = sum;
+    }
+    // (the first __syncthreads of the loop below orders these writes before any read)
     for (int q0 = 0; q0 < L; q0 += 64) {
         __syncthreads();
         load_tile<D>(Qt, base, q0, L, ld, t);
@@ -322,6 +338,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     }
 }
 
+// blockIdx.z = 0: dQ (and delta, kept as an output), 1: dK and dV
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                       const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                       float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (blockIdx.z == 0) attn_bwd_dq_body<D>(lds, qkv, o, d_o, lse, delta, dqkv, L, scale);
+    else attn_bwd_dkv_body<D>(lds, qkv, o, d_o, lse, dqkv, L, scale);
+}
+
 template <int D>
 static int attn_launch(int which, const bf16_t* qkv, bf16_t* o, const bf16_t* d_o, float* lse, float* delta, bf16_t* dqkv,
                        int N, int L, float scale, hipStream_t s) {
@@ -329,16 +355,16 @@ static int attn_launch(int which, const bf16_t* qkv, bf16_t* o, const bf16_t* d_
     static bool configured = false;
     if (!configured) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes + 4 * 4096));
         configured = true;
     }
     dim3 grid((unsigned)cdiv(L, 64), (unsigned)N);
     if (which == 0) {
         hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), bytes, s, qkv, o, lse, L, scale);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), grid, dim3(256), bytes, s, qkv, (const bf16_t*)o, d_o, (const float*)lse, delta, dqkv, L, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), grid, dim3(256), bytes, s, qkv, d_o, (const float*)lse, (const float*)delta, dqkv, L, scale);
+        MDM_REQUIRE(L <= 4096, "attention backward: L=%d > 4096", L);
+        hipLaunchKernelGGL((attn_bwd_kernel<D>), dim3(grid.x, grid.y, 2), dim3(256), bytes + 4 * L, s, qkv, (const bf16_t*)o, d_o,
+                           (const float*)lse, delta, dqkv, L, scale);
     }
     return launch_status("attention");
 }

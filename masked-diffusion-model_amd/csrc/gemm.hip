@@ -471,6 +471,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
             if (n < d.N) epilogue4<float>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
         }
     }
+    // bias gradient of a linear layer next to its weight gradient (layout 2, no gather): dbias[m] += sum_k A[k][m] over this
+    // workgroup's k-range, by the workgroups of the first column tile -- the k-rows are few (the batch) and just went through L2
+    if (LAYOUT == 2 && d.dbias && !d.conv && n0 == 0 && t < BM && m0 + t < d.M) {
+        float sum = 0.f;
+        const float* p = reinterpret_cast<const float*>(d.A) + z.batch * d.sA + m0 + t;
+        for (int k = z.kbeg; k < z.kend; ++k) sum += p[(int64_t)k * d.lda];
+        atomicAdd(&d.dbias[m0 + t], sum);
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -2164,7 +2172,8 @@ static int validate(const mdm_gemm_desc& d) {
         MDM_REQUIRE(d.lda % vec == 0 && d.ldb % vec == 0, "gemm: operand pitch must be a multiple of %d", vec);
     }
     if (d.rowvec) MDM_REQUIRE(d.rows_per_img > 0 && d.rv_ld % 4 == 0, "gemm: bad rowvec params");
-    if (d.dbias) MDM_REQUIRE(d.layout == 2 && d.dtype == MDM_BF16, "gemm: dbias is fused only into the bf16 layout-2 kernel");
+    if (d.dbias) MDM_REQUIRE(d.layout == 2 && (d.dtype == MDM_BF16 || (!d.conv && d.batch == 1)),
+                             "gemm: dbias is fused into the bf16 layout-2 kernels and the fp32 layout-2 kernel without a gather");
     if (d.resid) MDM_REQUIRE(d.ldr % 4 == 0, "gemm: bad resid pitch");
     if (d.splitk > 1) MDM_REQUIRE(d.out_f32 || d.dtype == MDM_F32, "gemm: split-K needs an fp32 destination");
     if (d.splitk > 1 && d.layout != 2 && !d.conv)

@@ -64,6 +64,10 @@ _PROTOS = {
     "mdm_timestep_embedding2": ([vp, i32, i32, i32, f32, vp, vp], i32),
     "mdm_silu_fwd": ([vp, vp, i64, vp], i32),
     "mdm_silu_bwd": ([vp, vp, vp, i32, i64, vp], i32),
+    "mdm_skinny_supported": ([i32, i32, i32, i32], i32),
+    "mdm_skinny_linear_fwd": ([vp, i32, vp, i32, f32, vp, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp], i32),
+    "mdm_skinny_linear_bwd": ([vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp], i32),
+    "mdm_silu_bwd_sum": ([vp, vp, i32, i64, vp, vp], i32),
     "mdm_colsum": ([i32, vp, i32, i32, i32, vp, i32, i32, vp, vp], i32),
     "mdm_sumpool2": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_add": ([i32, vp, vp, i64, vp], i32),

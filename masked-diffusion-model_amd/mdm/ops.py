@@ -162,10 +162,30 @@ def wgrad_group_split(g: ConvGeom, slabs_per_item=48):
 
 
 def matmul(dt, layout, M, N, K, A, lda, B, ldb, D, ldd, batch=1, sA=0, sB=0, sD=0, alpha=1.0, bias=None,
-           acc=0, out_f32=0, splitk=1):
-    """Plain (batched) contraction in one of the three layouts (see mdm_hip.h)."""
+           acc=0, out_f32=0, splitk=1, dbias=None):
+    """Plain (batched) contraction in one of the three layouts (see mdm_hip.h).  dbias (layout 2): += column sums of A."""
     _lib.gemm(dtype=dt, layout=layout, M=M, N=N, K=K, batch=batch, sA=sA, sB=sB, sD=sD, A=A, lda=lda, B=B, ldb=ldb,
-              D0=D, ldd0=ldd, N0=N, alpha=alpha, bias=bias, acc0=acc, out_f32=out_f32, splitk=splitk)
+              D0=D, ldd0=ldd, N0=N, alpha=alpha, bias=bias, acc0=acc, out_f32=out_f32, splitk=splitk, dbias=dbias)
+
+
+def skinny_supported(M, N, K, splits=1):
+    return bool(_lib.load().mdm_skinny_supported(M, N, K, splits))
+
+
+def skinny_linear_fwd(x, W, bias, M, N, K, y, act_out=None, t=None, variant=None, emb_out=None):
+    """y = x W^T + bias (fp32, M = batch rows), act_out = silu(y); x=None: the input is the timestep embedding of t."""
+    flip, shift = (0, 1.0) if variant is None else (int(bool(variant[0])), float(variant[1]))
+    call("mdm_skinny_linear_fwd", ptr(x), K, ptr(t), flip, shift, ptr(emb_out), ptr(W), K, ptr(bias), M, N, K, ptr(y), N,
+         ptr(act_out), stream())
+
+
+def skinny_linear_bwd(dy, W, M, N, K, dx=None, pre=None, splits=1, slabs=None):
+    """dx = dy W (* silu'(pre)); splits > 1: partial sums to slabs[splits][M][N] for silu_bwd_sum."""
+    call("mdm_skinny_linear_bwd", ptr(dy), K, ptr(W), N, M, N, K, splits, ptr(pre), ptr(dx), ptr(slabs), stream())
+
+
+def silu_bwd_sum(pre, slabs, nslab, n, dx):
+    call("mdm_silu_bwd_sum", ptr(pre), ptr(slabs), nslab, n, ptr(dx), stream())
 
 
 def groupnorm_fwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, y, stats, ws, G=32, eps=1e-6):

@@ -385,11 +385,23 @@ class _Temb:
         st.declare(self.l2 + ".weight", "lin", (self.temb, self.temb), (self.temb, self.temb))
         st.declare(self.l2 + ".bias", "vec", (self.temb,), (self.temb,))
 
+    def _skinny(self):
+        """The dedicated small-batch kernels (mdm_skinny_*) take this path; larger batches use the general contraction."""
+        n = self.net
+        return (self.hid % 2 == 0 and ops.skinny_supported(n.N, self.temb, self.hid) and ops.skinny_supported(n.N, self.temb, self.temb)
+                and ops.skinny_supported(n.N, self.fc_total, self.temb) and ops.skinny_supported(n.N, self.temb, self.fc_total))
+
     def fwd(self):
         n, st = self.net, self.net.store
         N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
         f = lambda *s: n.alloc(s, torch.float32)
         self.e, self.h1, self.a1, self.tm, self.st_ = f(N, hid), f(N, te), f(N, te), f(N, te), f(N, te)
+        if self._skinny():      # 3 launches: embedding + Linear + SiLU, Linear + SiLU, the 22 projections
+            ops.skinny_linear_fwd(None, st.f(self.l1 + ".weight"), st.f(self.l1 + ".bias"), N, te, hid, self.h1, act_out=self.a1,
+                                  t=n.t_in, variant=self.variant, emb_out=self.e)
+            ops.skinny_linear_fwd(self.a1, st.f(self.l2 + ".weight"), st.f(self.l2 + ".bias"), N, te, te, self.tm, act_out=self.st_)
+            ops.skinny_linear_fwd(self.st_, n.fc_w, n.fc_b, N, ft, te, n.T_all)
+            return
         ops.timestep_embedding(n.t_in, N, hid, self.e, self.variant)
         ops.matmul(F32, 0, N, te, hid, self.e, hid, st.f(self.l1 + ".weight"), hid, self.h1, te, bias=st.f(self.l1 + ".bias"))
         ops.silu_fwd(self.h1, self.a1, N * te)
@@ -402,6 +414,17 @@ class _Temb:
         N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
         f = lambda *s: n.alloc(s, torch.float32)
         d_st, d_tm, d_a1, d_h1 = f(N, te), f(N, te), f(N, te), f(N, te)
+        if self._skinny():      # 6 launches: bias gradients ride on the weight gradients, silu' on the data gradients
+            splits = max(s_ for s_ in range(1, 17) if (ft // 64) % s_ == 0)
+            slabs = f(splits, N, te)
+            ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1, dbias=n.fc_gb)
+            ops.skinny_linear_bwd(n.dT_all, n.fc_w, N, te, ft, dx=d_tm, pre=self.tm, splits=splits, slabs=slabs)
+            if splits > 1:
+                ops.silu_bwd_sum(self.tm, slabs, splits, N * te, d_tm)
+            ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g(self.l2 + ".weight"), te, acc=1, out_f32=1, dbias=st.g(self.l2 + ".bias"))
+            ops.skinny_linear_bwd(d_tm, st.f(self.l2 + ".weight"), N, te, te, dx=d_h1, pre=self.h1)
+            ops.matmul(F32, 2, te, hid, N, d_h1, te, self.e, hid, st.g(self.l1 + ".weight"), hid, acc=1, out_f32=1, dbias=st.g(self.l1 + ".bias"))
+            return
         ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1)
         ops.colsum(F32, n.dT_all, 1, N, ft, dbias=n.fc_gb)
         ops.fill(d_st, 0.0)                                   # K = sum(Cout) ~ 5k against M = batch: split the reduction

@@ -250,6 +250,58 @@ def test_skinny_fp32_linear(M, N, K):
     assert _relerr(D, want) < 1e-5
 
 
+@pytest.mark.parametrize("M", [4, 32, 100])
+@pytest.mark.parametrize("variant", [None, (True, 0.0)])
+def test_time_embedding_path_kernels(M, variant):
+    """mdm_skinny_linear_fwd / _bwd / mdm_silu_bwd_sum and the bias gradient riding on the fp32 weight gradient (the
+    time-embedding path, unet6.py:18-34, 395-399, 350, 359) against fp32 torch: embedding + Linear + SiLU in one launch,
+    Linear with a second silu output, the wide projection layer, the split data gradient and the silu' epilogues."""
+    from mdm import ops
+    hid, te, ft = 128, 512, 4992
+    g = torch.Generator().manual_seed(M)
+    t = torch.randint(1, 1001, (M,), generator=g).float()
+    W1, b1 = torch.randn(te, hid, generator=g) * 0.05, torch.randn(te, generator=g) * 0.1
+    W2, b2 = torch.randn(te, te, generator=g) * 0.05, torch.randn(te, generator=g) * 0.1
+    W3, b3 = torch.randn(ft, te, generator=g) * 0.05, torch.randn(ft, generator=g) * 0.1
+    dT = torch.randn(M, ft, generator=g) * 0.1
+    # reference
+    half = hid // 2
+    flip, shift = (False, 1.0) if variant is None else variant
+    f = torch.exp(-torch.arange(half, dtype=torch.float32) * (math.log(10000.0) / (half - shift)))
+    ang = t[:, None] * f[None]
+    e = torch.cat([torch.cos(ang), torch.sin(ang)] if flip else [torch.sin(ang), torch.cos(ang)], 1)
+    leaves = [x.clone().requires_grad_(True) for x in (W1, b1, W2, b2, W3, b3)]
+    h1 = e @ leaves[0].T + leaves[1]
+    tm = F.silu(h1) @ leaves[2].T + leaves[3]
+    T_all = F.silu(tm) @ leaves[4].T + leaves[5]
+    (T_all * dT).sum().backward()
+    # device
+    DEV = _dev()
+    d = lambda x: x.to(DEV).contiguous()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    tD, W1d, b1d, W2d, b2d, W3d, b3d, dTd = map(d, (t, W1, b1, W2, b2, W3, b3, dT))
+    eD, h1D, a1D, tmD, stD, TD = z(M, hid), z(M, te), z(M, te), z(M, te), z(M, te), z(M, ft)
+    assert ops.skinny_supported(M, te, hid) and ops.skinny_supported(M, ft, te) and ops.skinny_supported(M, te, ft, 13)
+    ops.skinny_linear_fwd(None, W1d, b1d, M, te, hid, h1D, act_out=a1D, t=tD, variant=variant, emb_out=eD)
+    ops.skinny_linear_fwd(a1D, W2d, b2d, M, te, te, tmD, act_out=stD)
+    ops.skinny_linear_fwd(stD, W3d, b3d, M, ft, te, TD)
+    torch.cuda.synchronize()
+    # sin / cos of arguments up to 1000 rad: the device's range reduction differs from the host's in the last bits
+    assert _relerr(eD, e) < 2e-4 and _relerr(h1D, h1.detach()) < 2e-4 and _relerr(a1D, F.silu(h1).detach()) < 2e-4
+    assert _relerr(tmD, tm.detach()) < 2e-4 and _relerr(TD, T_all.detach()) < 2e-4
+    gW3, gb3, gW2, gb2, gW1, gb1 = z(ft, te), z(ft), z(te, te), z(te), z(te, hid), z(te)
+    slabs, d_tm, d_h1 = z(13, M, te), z(M, te), z(M, te)
+    ops.matmul(0, 2, ft, te, M, dTd, ft, stD, te, gW3, te, acc=1, out_f32=1, dbias=gb3)
+    ops.skinny_linear_bwd(dTd, W3d, M, te, ft, splits=13, slabs=slabs)
+    ops.silu_bwd_sum(tmD, slabs, 13, M * te, d_tm)
+    ops.matmul(0, 2, te, te, M, d_tm, te, a1D, te, gW2, te, acc=1, out_f32=1, dbias=gb2)
+    ops.skinny_linear_bwd(d_tm, W2d, M, te, te, dx=d_h1, pre=h1D)
+    ops.matmul(0, 2, te, hid, M, d_h1, te, eD, hid, gW1, hid, acc=1, out_f32=1, dbias=gb1)
+    torch.cuda.synchronize()
+    for got, want in zip((gW1, gb1, gW2, gb2, gW3, gb3), leaves):
+        assert _relerr(got, want.grad) < 5e-4, _relerr(got, want.grad)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(3, 64, 64, 256), (2, 16, 16, 64), (2, 256, 256, 64), (1, 40, 72, 136)])
 def test_batched_matmul_layouts(dt, shape):
