@@ -357,14 +357,6 @@ int mdm_graph_end(void* stream, void** graph_exec_out);
 int mdm_graph_launch(void* graph_exec, void* stream);
 int mdm_graph_destroy(void* graph_exec);
 
-/* Fork/join for launches that are independent of the main chain (the weight gradient and bias sums of a
- * convolution next to its data gradient).  mdm_fork: a library-owned side stream waits for everything
- * enqueued on `stream` so far; until mdm_side_end, mdm_gemm and mdm_colsum go to the side stream.
- * mdm_join: `stream` waits for the side stream.  Under capture these become parallel hipGraph branches. */
-int mdm_fork(void* stream);
-int mdm_side_end(void* stream);
-int mdm_join(void* stream);
-
 /* HIP events on a caller-supplied stream (bench.py times kernels on the launch stream) */
 int mdm_event_create(void** ev);
 int mdm_event_record(void* ev, void* stream);

@@ -27,7 +27,7 @@ int hip_fail(hipError_t e, const char* what);
         }                                      \
     } while (0)
 
-hipStream_t pick_stream(void* stream);     // main stream, or the side stream between mdm_fork() and mdm_side_end()
+inline hipStream_t pick_stream(void* stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();

@@ -29,39 +29,6 @@ extern "C" int mdm_device_count(void) {
     return n;
 }
 
-// ---- fork/join: a second stream for launches that are independent of the main chain (e.g. the weight
-// gradient of a convolution next to its data gradient).  Under stream capture the event edges become
-// graph dependencies, so the two kernels are parallel branches of the hipGraph.
-namespace mdm {
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_fork_ev = nullptr, g_join_ev = nullptr;
-static thread_local bool g_on_side = false;
-hipStream_t pick_stream(void* stream) { return (g_on_side && g_side) ? g_side : reinterpret_cast<hipStream_t>(stream); }
-}  // namespace mdm
-
-extern "C" int mdm_fork(void* stream) {
-    if (!g_side) {
-        MDM_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-        MDM_CHECK_HIP(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
-        MDM_CHECK_HIP(hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming));
-    }
-    MDM_CHECK_HIP(hipEventRecord(g_fork_ev, (hipStream_t)stream));
-    MDM_CHECK_HIP(hipStreamWaitEvent(g_side, g_fork_ev, 0));
-    g_on_side = true;               // launches that honour pick_stream() now go to the side stream
-    return 0;
-}
-extern "C" int mdm_side_end(void* stream) {   // back to the main stream; the side work keeps running
-    g_on_side = false;
-    return 0;
-}
-extern "C" int mdm_join(void* stream) {
-    g_on_side = false;
-    MDM_REQUIRE(g_side != nullptr, "join without fork");
-    MDM_CHECK_HIP(hipEventRecord(g_join_ev, g_side));
-    MDM_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, g_join_ev, 0));
-    return 0;
-}
-
 extern "C" int mdm_graph_begin(void* stream) {
     MDM_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     return 0;

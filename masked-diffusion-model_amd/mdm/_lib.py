@@ -92,9 +92,6 @@ _PROTOS = {
     "mdm_transpose_shadow": ([vp, vp, vp, i32, vp], i32),
     "mdm_transpose_shadow_bf16": ([vp, vp, vp, i32, vp], i32),
     "mdm_fill_f32": ([vp, f32, i64, vp], i32),
-    "mdm_fork": ([vp], i32),
-    "mdm_side_end": ([vp], i32),
-    "mdm_join": ([vp], i32),
     "mdm_graph_begin": ([vp], i32),
     "mdm_graph_end": ([vp, C.POINTER(vp)], i32),
     "mdm_graph_launch": ([vp, vp], i32),
@@ -179,8 +176,6 @@ class Recording:
         lib = load()
         pairs = []
         for i, (name, fn, args) in enumerate(self.calls):
-            if name in ("mdm_fork", "mdm_side_end", "mdm_join"):
-                continue            # timed replay is serial on `st`, so the event pairs bracket every launch
             if pick(i, name):
                 a, b = vp(), vp()
                 check(lib.mdm_event_create(C.byref(a))); check(lib.mdm_event_create(C.byref(b)))
