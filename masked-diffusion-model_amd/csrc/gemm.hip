@@ -112,6 +112,19 @@ struct ZInfo { int batch, tap, kbeg, kend, ks, outer, nouter; };   // nouter: ta
 // XCD x the x-th CONTIGUOUS eighth of the work items instead, so items that read the same operand slices
 // (the filter taps and output tiles of one k-range; neighbouring pixel tiles and the column tiles of one
 // pixel tile) meet in one L2.
+// x / dv for a WAVE-UNIFORM x >= 0 and dv in [1, 2^10]: a float reciprocal estimate (one v_rcp, off by at most one for x < 2^22)
+// and one correction step, instead of the ~25 dependent scalar instructions of an integer division
+__device__ __forceinline__ int udiv_small(int x, int dv) {
+    int q = (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)dv));
+    const int r = x - q * dv;
+    q += r >= dv ? 1 : (r < 0 ? -1 : 0);
+    return q;
+}
+// m / rows for a row count that is a power of two wherever a convolution supplies it (rows per image = OH * OW)
+__device__ __forceinline__ int div_rows(int m, int rows) {
+    return (rows & (rows - 1)) == 0 ? m >> __builtin_ctz(rows) : m / rows;
+}
+
 __device__ __forceinline__ int xcd_remap(int lin, int total) {
     const int q = total >> 3, r = total & 7, x = lin & 7, w = lin >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
@@ -146,7 +159,7 @@ __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
     if (d.rowvec) {
-        float4 b = *reinterpret_cast<const float4*>(d.rowvec + (int64_t)(m / d.rows_per_img) * d.rv_ld + n);
+        float4 b = *reinterpret_cast<const float4*>(d.rowvec + (int64_t)div_rows(m, d.rows_per_img) * d.rv_ld + n);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
     if (d.resid) {
@@ -1104,7 +1117,7 @@ __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds,
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = row_w + i * 16 + (lane & 15), m = m0 + ml;
-        const float* rv = (d.rowvec && m < d.M) ? d.rowvec + (int64_t)(m / d.rows_per_img) * d.rv_ld : nullptr;
+        const float* rv = (d.rowvec && m < d.M) ? d.rowvec + (int64_t)div_rows(m, d.rows_per_img) * d.rv_ld : nullptr;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int nl = col_w + j * 16 + 4 * (lane >> 4), n = n0 + nl;
@@ -1199,9 +1212,11 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     }
     if (t < 128) gs[t] = 0.f;
     __syncthreads();
-    const int C = d.N, G = d.gnb_G, cpg = C / G, P = d.OH * d.OW;          // P = 16 or 64 pixels per image
-    const int r = t >> 3, q = t & 7, il = r / P;
-    const int m = m0 + r, n = n0 + q * 8, img = m0 / P + il;
+    // P = 16 or 64 pixels per image, cpg = 4 .. 64 channels per group: powers of two (mdm_gemm_can_fuse_gn_bwd), so the
+    // per-element group index is a shift (it was 16 integer divisions per thread)
+    const int C = d.N, G = d.gnb_G, P = d.OH * d.OW, p_sh = __builtin_ctz(P), cpg_sh = __builtin_ctz(C) - __builtin_ctz(G), cpg = 1 << cpg_sh;
+    const int r = t >> 3, q = t & 7, il = r >> p_sh;
+    const int m = m0 + r, n = n0 + q * 8, img = (m0 >> p_sh) + il;
     const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
     const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
     const float dz[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -1214,7 +1229,7 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     float rstd[8], xh[8], gz[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + (n + e) / cpg) * 2);
+        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + ((n + e) >> cpg_sh)) * 2);
         rstd[e] = st.y;
         xh[e] = (xv[e] - st.x) * st.y;
         gz[e] = dz[e];
@@ -1243,7 +1258,7 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     }
     {                                    // group sums per image: (image il2, channel c) -> gs[il2][group][0/1]
         const int ppi = P >> 4;          // parts per image (1 or 4)
-        const int nimg = 64 / P;
+        const int nimg = 64 >> p_sh;
         if (t < nimg * 64) {
             const int il2 = t >> 6, c = t & 63;
 #pragma unroll
@@ -1251,7 +1266,7 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
                 const int col = ((8 * w + (c & 7)) << 3) + (c >> 3);
                 float v = 0.f;
                 for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
-                atomicAdd(&gs[(il2 * 16 + c / cpg) * 2 + w], v);
+                atomicAdd(&gs[(il2 * 16 + (c >> cpg_sh)) * 2 + w], v);
             }
         }
     }
@@ -1260,7 +1275,7 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int gl = (q * 8 + e) / cpg;
+        const int gl = (q * 8 + e) >> cpg_sh;
         const float k1 = rstd[e] * gs[(il * 16 + gl) * 2] * inv_cnt, k2 = rstd[e] * gs[(il * 16 + gl) * 2 + 1] * inv_cnt;
         o[e] = rstd[e] * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
     }
@@ -1289,12 +1304,12 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
             psum[t] = sum;
         }
         __syncthreads();
-        const int ppi = P >> 4, nimg = 64 / P;
+        const int ppi = P >> 4, nimg = 64 >> p_sh;
         if (t < nimg * 64) {
             const int il2 = t >> 6, c = t & 63, col = ((c & 7) << 3) + (c >> 3);
             float v = 0.f;
             for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
-            if (d.gnb_sum_img) d.gnb_sum_img[(int64_t)(m0 / P + il2) * d.gnb_sum_ld + n0 + c] = v;      // this workgroup owns (image, channel)
+            if (d.gnb_sum_img) d.gnb_sum_img[(int64_t)((m0 >> p_sh) + il2) * d.gnb_sum_ld + n0 + c] = v;      // this workgroup owns (image, channel)
             if (d.gnb_sum_all) atomicAdd(d.gnb_sum_all + n0 + c, v);
         }
     }
@@ -1319,7 +1334,7 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = row_w + i * 16 + (lane & 15), mrow = m0 + ml;
-        const float* rv = (d.rowvec && mrow < d.M) ? d.rowvec + (int64_t)(mrow / d.rows_per_img) * d.rv_ld : nullptr;
+        const float* rv = (d.rowvec && mrow < d.M) ? d.rowvec + (int64_t)div_rows(mrow, d.rows_per_img) * d.rv_ld : nullptr;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int nl = col_w + j * 16 + 4 * (lane >> 4), ncol = n0 + nl;
@@ -1331,8 +1346,8 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
     }
     if (t < 64) gs[t] = 0.f;
     __syncthreads();
-    const int C = d.N, G = d.gnf_G, cpg = C / G, P = d.OH * d.OW;
-    const int r = t >> 3, q = t & 7, il = r / P;
+    const int C = d.N, G = d.gnf_G, P = d.OH * d.OW, p_sh = __builtin_ctz(P), cpg_sh = __builtin_ctz(C) - __builtin_ctz(G), cpg = 1 << cpg_sh;
+    const int r = t >> 3, q = t & 7, il = r >> p_sh;             // powers of two (mdm_gemm_can_fuse_gn_fwd): shifts, not divisions
     const int m = m0 + r, n = n0 + q * 8;
     const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
     const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
@@ -1349,7 +1364,7 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
     float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) y[e] = bf2f(f2bf(vv[e]));
-    const int ppi = P >> 4, nimg = 64 / P;
+    const int ppi = P >> 4, nimg = 64 >> p_sh;
     const float inv_cnt = 1.f / ((float)cpg * (float)P);
     float mean[8], rstd[8];
 #pragma unroll
@@ -1370,7 +1385,7 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
             const int il2 = t >> 6, c = t & 63, col = ((c & 7) << 3) + (c >> 3);
             float s2 = 0.f;
             for (int pp = 0; pp < ppi; ++pp) s2 += psum[col * 4 + il2 * ppi + pp];
-            atomicAdd(&gs[il2 * 16 + c / cpg], s2);
+            atomicAdd(&gs[il2 * 16 + (c >> cpg_sh)], s2);
         }
         __syncthreads();
         if (t < 64) {
@@ -1379,12 +1394,12 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
         __syncthreads();
         if (pass == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mean[e] = gm[il * 16 + (q * 8 + e) / cpg];
+            for (int e = 0; e < 8; ++e) mean[e] = gm[il * 16 + ((q * 8 + e) >> cpg_sh)];
             if (t < 64) gs[t] = 0.f;
             __syncthreads();
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rstd[e] = gr[il * 16 + (q * 8 + e) / cpg];
+            for (int e = 0; e < 8; ++e) rstd[e] = gr[il * 16 + ((q * 8 + e) >> cpg_sh)];
         }
     }
     const float4 g_lo = *reinterpret_cast<const float4*>(d.gnf_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnf_gamma + n + 4);
@@ -1399,10 +1414,10 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
     }
     const float8 zo = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
     store8(reinterpret_cast<bf16_t*>(d.gnf_out) + (int64_t)m * C + n, zo);
-    const int ngt = 64 / cpg;                                              // groups inside this 64-channel tile
+    const int ngt = 64 >> cpg_sh;                                          // groups inside this 64-channel tile
     if (t < nimg * ngt) {
-        const int il2 = t / ngt, gl = t - il2 * ngt;
-        float* sp = d.gnf_stats + ((int64_t)(m0 / P + il2) * G + n0 / cpg + gl) * 2;
+        const int il2 = t >> (6 - cpg_sh), gl = t - il2 * ngt;
+        float* sp = d.gnf_stats + ((int64_t)((m0 >> p_sh) + il2) * G + (n0 >> cpg_sh) + gl) * 2;
         sp[0] = gm[il2 * 16 + gl]; sp[1] = gr[il2 * 16 + gl];
     }
 }
@@ -1437,7 +1452,8 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
     const int tiles_n = (d.N + BN - 1) / BN;
     const int tile_i = xcd_remap((int)blockIdx.x, (int)gridDim.x);     // XCD-aware tile order: see conv_halo_kernel
-    const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
+    const int tile_m = udiv_small(tile_i, tiles_n);                    // (scalar integer divisions cost ~200 cycles each here)
+    const int m0 = tile_m * BM, n0 = (tile_i - tile_m * tiles_n) * BN;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int sk = d.splitk < 1 ? 1 : d.splitk;
     ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.nouter = 1; z.ks = blockIdx.z;
@@ -1477,9 +1493,9 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
     }
 
     // ---- issue cursor (all wave-uniform): filter tap, source, channel; one live pointer per piece
-    const int tps = ntaps / sk;
+    const int tps = udiv_small(ntaps, sk);
     const int tap_beg = z.ks * tps;
-    int i_tap = tap_beg, i_ty = tap_beg / d.KW, i_tx = tap_beg - (tap_beg / d.KW) * d.KW, i_src = 0, i_c = 0;
+    int i_tap = tap_beg, i_ty = udiv_small(tap_beg, d.KW), i_tx = tap_beg - i_ty * d.KW, i_src = 0, i_c = 0;
     const int nk = tps * (d.Ck / BK);
     int issued = 0;
     int i_stage = 0;                    // byte offset of the stage the next issue fills
@@ -1978,12 +1994,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     const int wr = wave / WC, wc = wave % WC;
     const int OW = d.OW, OH = d.OH, HW2 = OW + 2;
     // the tile is R image rows of one image, or (maps of <= BM pixels) IMGS whole images with one halo block each
-    const int IMGS = BM > OH * OW ? BM / (OH * OW) : 1, R = IMGS > 1 ? OH : BM / OW;
+    // OW and OH are powers of two (halo_tile): every division by them is a shift.  The prologue of this kernel was ~480
+    // instructions before its first DMA, most of them eight scalar integer divisions in a dependent chain (~3000 cycles).
+    const int ow_sh = __builtin_ctz(OW), p_sh = ow_sh + __builtin_ctz(OH);
+    const int IMGS = BM > (1 << p_sh) ? BM >> p_sh : 1, R = IMGS > 1 ? OH : BM >> ow_sh;
     const int HRI = (R + 2) * HW2, HR = IMGS * HRI, NPA = (HR + 7) >> 3, ABUF = NPA * 1024;
-    // per-lane index arithmetic below divides by HW2 and HRI (not powers of two): multiply-shift with a 20-bit
-    // reciprocal M = ceil(2^20 / d), exact while x * (M * d - 2^20) < 2^20: here x < 800, d <= 400
-    const unsigned rcp_hw2 = ((1u << 20) + HW2 - 1) / HW2, rcp_hri = ((1u << 20) + HRI - 1) / HRI;
-    const int ow_sh = __builtin_ctz(OW), rows_sh = __builtin_ctz(R * OW);       // OW, R * OW are powers of two
+    // per-lane index arithmetic below divides by HW2 and HRI (not powers of two): (x + 0.5) * rcp(d) truncated is exact while
+    // the 1-ulp error of v_rcp times x / d stays under 0.5 / d: here x < 800, d <= 400
+    const float inv_hw2 = __builtin_amdgcn_rcpf((float)HW2), inv_hri = __builtin_amdgcn_rcpf((float)HRI);
+    const int rows_sh = __builtin_ctz(R) + ow_sh;                               // R * OW is a power of two
     char* const bring = lds + 2 * ABUF;
     char* const dummy = bring + NSB * STAGE_B;
     const int tiles_n = d.N / BN;
@@ -1992,8 +2011,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     // instead of eight.  No effect on time at cfg2 (the loop is bound by the CU's intake, not by L2 misses); it is there
     // for the L2-side traffic (FETCH_SIZE), which counts every XCD's own fetch of the same line.
     const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int mt = bid / tiles_n, n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
-    const int img = m0 / (OH * OW), y0 = (m0 / OW) % OH;
+    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
+    const int img = m0 >> p_sh, y0 = (m0 >> ow_sh) & (OH - 1);
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int NCS = d.Ck / 64;                       // 64-channel slabs over both sources
     const int sgn = d.transposed ? -1 : 1;
@@ -2004,8 +2023,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
         const int hr = (wave + 8 * k) * 8 + (lane >> 3);
-        const int il = (int)(((unsigned)hr * rcp_hri) >> 20), hrem = hr - il * HRI;
-        const int hy = (int)(((unsigned)hrem * rcp_hw2) >> 20), hx = hrem - hy * HW2;
+        const int il = (int)(((float)hr + 0.5f) * inv_hri), hrem = hr - il * HRI;
+        const int hy = (int)(((float)hrem + 0.5f) * inv_hw2), hx = hrem - hy * HW2;
         const int y = y0 - 1 + hy, x = hx - 1;
         const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M;
         // folded nearest x2 upsample (unet6.py:472): the map the conv sees is virtual, pixel (y, x) lives at (y>>1, x>>1)
@@ -2268,7 +2287,8 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filt
 static int halo_tile(const mdm_gemm_desc& d) {
     if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && (d.ups == 0 || d.ups == 1) &&
           !(d.ups && (d.transposed || d.C1)) && d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW &&
-          d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && !d.out_f32))
+          d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && !d.out_f32 &&
+          (d.OH & (d.OH - 1)) == 0))          // the kernel shifts by log2(OW), log2(OH)
         return 0;
     if (d.OW == 16 || d.OW == 32 || d.OW == 64) {
         for (int bm : {256, 128}) {

@@ -33,11 +33,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
                                                      float eps, const float* gamma, const float* beta, int silu, T* y,
                                                      float* stats) {
-    const int C = C0 + C1, cpg = C / G;
-    const int VB = CBLK / 8, PL = 256 / VB;
+    const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
+    const float inv_cpg = rcp_small(cpg);
+    const int VB = CBLK >> 3, PL = div_small(256, rcp_small(VB));
     const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
-    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
-    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const int t = threadIdx.x, lane = div_small(t, rcp_small(VB)), v = t - lane * VB, c = cb + v * 8;
+    const int ng = div_small(CBLK, inv_cpg), g0 = div_small(cb, inv_cpg);
     const bool on = t < VB * PL && c < C;
     __shared__ float gsum[2 * 64], gmean[64], grstd[64];
     if (t < 2 * ng) gsum[t] = 0.f;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
     if (on) {
         float s[8] = {}, q[8] = {}, K[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, (c + e) / cpg, cpg);
+        for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, div_small(c + e, inv_cpg), cpg);
         auto add = [&](const float8& x) {
             float xv[8] = F8_TO_ARR(x);
 #pragma unroll
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
         for (; p < P; p += PL) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
+            int gl = div_small(c + e, inv_cpg) - g0;
             atomicAdd(&gsum[2 * gl], s[e]);
             atomicAdd(&gsum[2 * gl + 1], q[e]);
         }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
         float m[8], a[8], bt[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
+            int gl = div_small(c + e, inv_cpg) - g0;
             m[e] = gmean[gl]; a[e] = grstd[gl] * gamma[c + e]; bt[e] = beta[c + e];
         }
         auto put = [&](int p, const float8& x) {
@@ -117,11 +118,12 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
                                                      const float* gamma, const float* beta, int silu, const T* dy,
                                                      const float* stats, T* d0, const T* add0, T* d1, const T* add1,
                                                      float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
-    const int C = C0 + C1, cpg = C / G;
-    const int VB = CBLK / 8, PL = 256 / VB;
+    const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
+    const float inv_cpg = rcp_small(cpg);
+    const int VB = CBLK >> 3, PL = div_small(256, rcp_small(VB));
     const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
-    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
-    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const int t = threadIdx.x, lane = div_small(t, rcp_small(VB)), v = t - lane * VB, c = cb + v * 8;
+    const int ng = div_small(CBLK, inv_cpg), g0 = div_small(cb, inv_cpg);
     const bool on = t < VB * PL && c < C;
     __shared__ float gsum[2 * 64];
     __shared__ float chan[2 * 64];           // per-channel dgamma / dbeta of this workgroup (CBLK <= 64)
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
     if (on) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int grp = (c + e) / cpg;
+            int grp = div_small(c + e, inv_cpg);
             ga[e] = gamma[c + e]; be[e] = beta[c + e];
             mean[e] = stats[((int64_t)img * G + grp) * 2]; rstd[e] = stats[((int64_t)img * G + grp) * 2 + 1];
         }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
         for (; p < P; p += PL) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * C + c));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
+            int gl = div_small(c + e, inv_cpg) - g0;
             atomicAdd(&gsum[2 * gl], a1[e]);
             atomicAdd(&gsum[2 * gl + 1], a2[e]);
             atomicAdd(&chan[v * 8 + e], dg[e]);
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
+            int gl = div_small(c + e, inv_cpg) - g0;
             k1[e] = rstd[e] * gsum[2 * gl] * inv_cnt;
             k2[e] = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
             ag[e] = rstd[e] * ga[e];
@@ -253,12 +255,12 @@ __device__ __forceinline__ void block_colsum(const float (&val)[K], float* scrat
     for (int k = 0; k < K; ++k) scratch[k * CS_PITCH + t] = val[k];
     __syncthreads();
     const int cols = K * VB;                       // <= 256
-    int tpc = 1;                                   // threads per column (power of two)
-    while (tpc * 2 * cols <= NT) tpc *= 2;
-    const int col = t / tpc, part = t - col * tpc;
+    int tpc = 1, tpc_sh = 0;                       // threads per column (power of two)
+    while (tpc * 2 * cols <= NT) { tpc *= 2; ++tpc_sh; }
+    const int col = t >> tpc_sh, part = t - (col << tpc_sh);
     float sum = 0.f;
     if (col < cols) {
-        const int k = col / VB, v = col - k * VB;
+        const int k = div_small(col, rcp_small(VB)), v = col - k * VB;
         // the tpc threads of a column take the pixel lanes INTERLEAVED (l = part, part + tpc, ...): neighbouring lanes then
         // read neighbouring LDS words.  (Contiguous shares put the threads of a column a multiple of 64 words apart --
         // 8-way bank conflicts, 62 % of the GroupNorm kernels' LDS cycles by SQ_LDS_BANK_CONFLICT.)
@@ -307,14 +309,15 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
                                                          float eps, const float* gamma, const float* beta, int silu, bf16_t* y,
                                                          float* stats, float* ws) {
     constexpr int CS_PITCH = NT + 4;
-    const int C = C0 + C1, cpg = C / G;
-    const int VB = CBLK / 8, PL = NT / VB;
+    const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
+    const float inv_cpg = rcp_small(cpg);
+    const int VB = CBLK >> 3, PL = div_small(NT, rcp_small(VB));
     const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
-    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
-    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const int t = threadIdx.x, lane = div_small(t, rcp_small(VB)), v = t - lane * VB, c = cb + v * 8;
+    const int ng = div_small(CBLK, inv_cpg), g0 = div_small(cb, inv_cpg);
     const bool on = t < VB * PL && c < C;
     const int chunks = gridDim.z, chunk = blockIdx.z;
-    const int plen = (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
+    const int plen = chunks == 1 ? P : (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
     __shared__ float scratch[16 * CS_PITCH];
     __shared__ float csum[16 * 8];
     __shared__ float gsum[2 * 64], gmean[64], grstd[64], gpiv[64];
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
     if (MODE != 2 && on) {
         float K[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) K[e] = gpiv[(c + e) / cpg - g0];
+        for (int e = 0; e < 8; ++e) K[e] = gpiv[div_small(c + e, inv_cpg) - g0];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (pbeg + lane + i * PL < pend) {
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
     if (MODE != 2) {
         block_colsum<16, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
         if (t < CBLK && cb + t < C) {
-            const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
+            const int vv = t >> 3, e = t & 7, gl = div_small(cb + t, inv_cpg) - g0;
             atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
             atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
         }
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
         const float bv[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
+            int gl = div_small(c + e, inv_cpg) - g0;
             m[e] = gmean[gl]; a[e] = grstd[gl] * gv[e]; bt[e] = bv[e];
         }
 #pragma unroll
@@ -418,14 +421,15 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
                                                          float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all,
                                                          float* ws) {
     constexpr int CS_PITCH = NT + 4;
-    const int C = C0 + C1, cpg = C / G;
-    const int VB = CBLK / 8, PL = NT / VB;
+    const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
+    const float inv_cpg = rcp_small(cpg);
+    const int VB = CBLK >> 3, PL = div_small(NT, rcp_small(VB));
     const int img = blockIdx.x, cb = blockIdx.y * CBLK;     // image fastest: the channel blocks of one image (they share 128-B lines) land on one XCD
-    const int t = threadIdx.x, v = t % VB, lane = t / VB, c = cb + v * 8;
-    const int ng = CBLK / cpg, g0 = cb / cpg;
+    const int t = threadIdx.x, lane = div_small(t, rcp_small(VB)), v = t - lane * VB, c = cb + v * 8;
+    const int ng = div_small(CBLK, inv_cpg), g0 = div_small(cb, inv_cpg);
     const bool on = t < VB * PL && c < C;
     const int chunks = gridDim.z, chunk = blockIdx.z;
-    const int plen = (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
+    const int plen = chunks == 1 ? P : (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
     __shared__ float scratch[32 * CS_PITCH];
     __shared__ float csum[32 * 8];
     __shared__ float gsum[2 * 64];
@@ -461,12 +465,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
             ga[0] = g_lo.x; ga[1] = g_lo.y; ga[2] = g_lo.z; ga[3] = g_lo.w; ga[4] = g_hi.x; ga[5] = g_hi.y; ga[6] = g_hi.z; ga[7] = g_hi.w;
             be[0] = b_lo.x; be[1] = b_lo.y; be[2] = b_lo.z; be[3] = b_lo.w; be[4] = b_hi.x; be[5] = b_hi.y; be[6] = b_hi.z; be[7] = b_hi.w;
             // 8 consecutive channels touch at most 8/cpg + 1 groups; load each group's pair once
-            const int gA = c / cpg;
+            const int gA = div_small(c, inv_cpg);
             float2 st_prev = *reinterpret_cast<const float2*>(stats + ((int64_t)img * G + gA) * 2);
             int g_prev = gA;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int grp = (c + e) / cpg;
+                const int grp = div_small(c + e, inv_cpg);
                 if (grp != g_prev) { st_prev = *reinterpret_cast<const float2*>(stats + ((int64_t)img * G + grp) * 2); g_prev = grp; }
                 mean[e] = st_prev.x; rstd[e] = st_prev.y;
             }
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
     if (MODE != 2) {
         block_colsum<32, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
         if (t < CBLK && cb + t < C) {
-            const int vv = t >> 3, e = t & 7, gl = (cb + t) / cpg - g0;
+            const int vv = t >> 3, e = t & 7, gl = div_small(cb + t, inv_cpg) - g0;
             atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
             atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
             atomicAdd(&dgamma[cb + t], csum[(16 + e) * VB + vv]);
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int gl = (c + e) / cpg - g0;
+            int gl = div_small(c + e, inv_cpg) - g0;
             k1[e] = rstd[e] * gsum[2 * gl] * inv_cnt;
             k2[e] = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
             ag[e] = rstd[e] * ga[e];
