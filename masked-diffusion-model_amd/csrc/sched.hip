@@ -34,13 +34,32 @@ __global__ void draw_timesteps_kernel(const uint64_t* rng, const int32_t* used, 
 __global__ __launch_bounds__(256) void degrade_kernel(const float* x0, const float* u, const float* mask_in,
                                                       const double* amount, int amount_stride, const uint64_t* rng,
                                                       int rng_stream, int C, int HW, int Cm, int fill_mode, float fill_const,
-                                                      float* x_t, float* mask, float* mean_pixel) {
+                                                      float* x_t, float* mask, float* mean_pixel, int keep_lds) {
     const int img = blockIdx.x, t = threadIdx.x;
     const double thr = amount ? amount[(int64_t)img * amount_stride] : 0.0;
     __shared__ float s_sum[8], s_cnt[8], s_fill[8];
+    // The keep flags of the image, drawn ONCE into LDS (keep_lds != 0: Cm * HW bytes fit and HW % 4 == 0): one Philox call
+    // yields the uniforms of 4 consecutive elements, and both passes and all C channels of a 1-channel mask read the same flag
+    // (computing it at every use cost 24 Philox calls per thread at cfg2).  Same uniforms, same fp64 comparison.
+    extern __shared__ unsigned char s_keep[];
+    if (keep_lds && !mask_in) {
+        for (int q = t; q < (Cm * HW) >> 2; q += 256) {
+            const int64_t e0 = (int64_t)img * Cm * HW + 4 * q;
+            float uv[4];
+            if (u) { uv[0] = u[e0]; uv[1] = u[e0 + 1]; uv[2] = u[e0 + 2]; uv[3] = u[e0 + 3]; }
+            else {
+                const uint4 r = philox_at(rng, rng_stream, (uint64_t)e0 >> 2);
+                uv[0] = u01(r.x); uv[1] = u01(r.y); uv[2] = u01(r.z); uv[3] = u01(r.w);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_keep[4 * q + j] = ((double)uv[j] > thr) ? 1 : 0;
+        }
+        __syncthreads();
+    }
     auto keep_at = [&](int c, int p) -> float {
         if (mask_in) return mask_in[((int64_t)img * C + c) * HW + p];
         int cm = Cm == 1 ? 0 : c;
+        if (keep_lds) return s_keep[cm * HW + p] ? 1.f : 0.f;
         float uv;
         if (u) uv = u[(int64_t)img * Cm * HW + (int64_t)cm * HW + p];
         else {
@@ -83,8 +102,9 @@ __global__ __launch_bounds__(256) void degrade_kernel(const float* x0, const flo
         __syncthreads();
     }
     if (mean_pixel && t < C) mean_pixel[(int64_t)img * C + t] = s_fill[t];
+    const float inv_hw = rcp_small(HW);
     for (int i = t; i < C * HW; i += 256) {
-        int c = i / HW, p = i - c * HW;
+        int c = (C * HW < (1 << 20) && HW <= 1024) ? div_small(i, inv_hw) : i / HW, p = i - c * HW;
         float k = keep_at(c, p);
         int64_t o = ((int64_t)img * C + c) * HW + p;
         if (x_t) x_t[o] = (1.f - k) * s_fill[c] + k * x0[o];
@@ -171,10 +191,20 @@ __global__ __launch_bounds__(256) void loss_kernel(const T* pred, const float* x
     const int64_t total = (int64_t)N * HW * Cp;
     const float inv_numel = 1.f / ((float)N * (float)C * (float)HW);
     float local = 0.f;
+    const bool small = total < (1ll << 31);       // 32-bit unsigned divisions (64-bit ones are ~100 instructions each)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int c = (int)(i % Cp);
-        int64_t pix = i / Cp;
-        int n = (int)(pix / HW), p = (int)(pix - (int64_t)n * HW);
+        int c, n, p;
+        if (small) {
+            const unsigned iu = (unsigned)i, pix = iu / (unsigned)Cp;
+            c = (int)(iu - pix * (unsigned)Cp);
+            n = (int)(pix / (unsigned)HW);
+            p = (int)(pix - (unsigned)n * (unsigned)HW);
+        } else {
+            c = (int)(i % Cp);
+            const int64_t pix = i / Cp;
+            n = (int)(pix / HW);
+            p = (int)(pix - (int64_t)n * HW);
+        }
         float g = 0.f;
         if (c < C) {
             int64_t o = ((int64_t)n * C + c) * HW + p;
@@ -267,8 +297,9 @@ extern "C" int mdm_degrade(const float* x0, const float* u, const float* mask_in
     MDM_REQUIRE(Cm == 1 || Cm == C, "degrade: Cm must be 1 or C");
     MDM_REQUIRE(fill_mode >= 0 && fill_mode <= 3, "degrade: bad fill_mode");
     MDM_REQUIRE(mask_in || (amount && (u || rng)), "degrade: need mask_in, or amount with u / rng");
-    hipLaunchKernelGGL(degrade_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x0, u, mask_in, amount, amount_stride, rng,
-                       rng_stream, C, HW, Cm, fill_mode, fill_const, x_t, mask, mean_pixel);
+    const int keep_lds = (!mask_in && HW % 4 == 0 && Cm * HW <= 48 * 1024) ? 1 : 0;
+    hipLaunchKernelGGL(degrade_kernel, dim3(N), dim3(256), keep_lds ? Cm * HW : 0, (hipStream_t)stream, x0, u, mask_in, amount,
+                       amount_stride, rng, rng_stream, C, HW, Cm, fill_mode, fill_const, x_t, mask, mean_pixel, keep_lds);
     return launch_status("degrade");
 }
 
@@ -312,7 +343,7 @@ extern "C" int mdm_loss_fwd_bwd(int dtype, const void* pred, const float* x_in, 
     MDM_REQUIRE(pred && x_in && x0 && loss_accum && Cp >= C, "loss: bad arguments");
     const int64_t total = (int64_t)N * H * W * Cp;
     int grid = sgrid(total);
-    if (grid > 1024) grid = 1024;
+    if (grid > 128) grid = 128;            // one same-address atomic per workgroup at the end: keep them few
     if (dtype == MDM_BF16)
         hipLaunchKernelGGL((loss_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, x_in, s, x0, w,
                            N, C, H * W, Cp, gscale, (bf16_t*)dpred, loss_accum);
