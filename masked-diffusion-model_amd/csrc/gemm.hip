@@ -1754,17 +1754,20 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
     const int tiles_n = (d.N + BN - 1) / BN;
     // work item order: k-range major, then filter tap, then output tile -- a contiguous run per XCD (xcd_remap)
     const int sk = d.splitk < 1 ? 1 : d.splitk, ntap = d.KH * d.KW, per_k = ntap * tiles_x;
-    const int ks_i = item / per_k, rem_i = item - ks_i * per_k, tap_i = rem_i / tiles_x, tile_i = rem_i - tap_i * tiles_x;
-    const int m0 = (tile_i / tiles_n) * BM, n0 = (tile_i % tiles_n) * BN;
+    // (wave-uniform quotients through udiv_small and shifts: seven scalar integer divisions cost ~1700 cycles per work item)
+    const int ks_i = udiv_small(item, per_k), rem_i = item - ks_i * per_k, tap_i = udiv_small(rem_i, tiles_x), tile_i = rem_i - tap_i * tiles_x;
+    const int tile_m = udiv_small(tile_i, tiles_n);
+    const int m0 = tile_m * BM, n0 = (tile_i - tile_m * tiles_n) * BN;
     ZInfo z; z.batch = 0; z.tap = tap_i; z.outer = tap_i; z.nouter = ntap; z.ks = ks_i; z.kbeg = 0; z.kend = d.K;
     if (sk > 1) {
-        const int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
+        const int chunk = (udiv_small(d.K + sk - 1, sk) + BK - 1) / BK * BK;
         z.kbeg = ks_i * chunk; z.kend = min(d.K, z.kbeg + chunk);
     }
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
-    const int ty = z.tap / d.KW, tx = z.tap - ty * d.KW;
+    const int ty = udiv_small(z.tap, d.KW), tx = z.tap - ty * d.KW;
     const int dyy = ty - d.pad_t, dxx = tx - d.pad_l;
-    const int rows_per_slab = BK / d.OW;
+    const int ow_sh = __builtin_ctz(d.OW), oh_sh = __builtin_ctz(d.OH);       // powers of two (wgrad_lin_eligible)
+    const int rows_per_slab = BK >> ow_sh;
     const int nk = (z.kend - z.kbeg) / BK;
 
     // ---- A = dY[k][m]: [64][BM] image, piece = A_RPP k-rows
@@ -1790,7 +1793,7 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
         const int kl = (wave * GB + j) * B_RPP + lane / BCPR;
         const int gn = n0 + 8 * ((lane % BCPR) ^ swz_cols<BCPR>(kl));
         const int k = z.kbeg + kl;
-        const int x = k % d.OW, y = (k / d.OW) & (d.OH - 1), img_i = k / (d.OH * d.OW);
+        const int x = k & (d.OW - 1), y = (k >> ow_sh) & (d.OH - 1), img_i = k >> (ow_sh + oh_sh);
         b_y[j] = y;
         // source pixel of output pixel (y, x) under tap (ty, tx): virtual (y s + dy, x s + dx), physical = virtual >> ups
         // (stride 2: unet6.py:257-272; folded nearest x2 upsample: unet6.py:472).  A slab is rows_per_slab whole output
