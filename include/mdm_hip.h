@@ -347,6 +347,10 @@ int mdm_transpose_shadow(const float* P, void* PT, const int64_t* tiles, int nti
 /* the same from the bf16 shadow Pb (element offsets identical): PT[off + c*Cout + r] = Pb[off + r*Cin + c] */
 int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, int ntiles, void* stream);
 int mdm_fill_f32(float* p, float v, int64_t n, void* stream);
+/* base[off .. off + len) = v for nseg segments segs[i] = {off, len} (device, int64 pairs; len % 4 == 0, len <= 4096, off % 4 == 0):
+ * the per-step zeroing of the ACCUMULATED gradient slots only (biases, GroupNorm scales: `optimizer.zero_grad()` at
+ * trainer_masked_shift.py:137 -- the weight gradients overwrite their slots, mdm_wgrad_group_*) */
+int mdm_fill_segments_f32(float* base, const int64_t* segs, int nseg, float v, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * hipGraph capture of a launch sequence issued on `stream` (the whole train step

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(mdm_gemm_desc d) {
             float4 b = w[(int64_t)s * total4];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        int m = total4 < (1ll << 31) ? (int)((unsigned)i / (unsigned)n4) : (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
         epilogue4<T>(e, z, m, n, a);
     }
 }

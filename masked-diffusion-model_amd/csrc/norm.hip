@@ -647,12 +647,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void sumpool2_kernel(const T* g, T* dst, int acc, int H, int W, int C, int64_t total_vec) {
     const int VPP = C / 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t pix = i / VPP;
-        int c = (int)(i - pix * VPP) * 8;
-        int x = (int)(pix % W);
-        int64_t r = pix / W;
-        int y = (int)(r % H);
-        int64_t img = r / H;
+        int64_t pix, img;
+        int c, x, y;
+        if (total_vec < (1ll << 31)) {          // 32-bit quotients (a 64-bit division is ~100 instructions)
+            const unsigned iu = (unsigned)i, pu = iu / (unsigned)VPP, ru = pu / (unsigned)W, mu = ru / (unsigned)H;
+            pix = pu; c = (int)(iu - pu * (unsigned)VPP) * 8; x = (int)(pu - ru * (unsigned)W); y = (int)(ru - mu * (unsigned)H); img = mu;
+        } else {
+            pix = i / VPP;
+            c = (int)(i - pix * VPP) * 8;
+            x = (int)(pix % W);
+            const int64_t r = pix / W;
+            y = (int)(r % H);
+            img = r / H;
+        }
         const T* base = g + (((img * 2 * H + 2 * y) * 2 * W) + 2 * x) * (int64_t)C + c;
         float8 a = load8(base), b = load8(base + C), cc = load8(base + (int64_t)2 * W * C), dd = load8(base + (int64_t)2 * W * C + C);
         float8 o;

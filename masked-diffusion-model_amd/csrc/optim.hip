@@ -109,6 +109,12 @@ __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
 __global__ void fill_kernel(float* p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
+// segs[i] = {element offset, length}; lengths are multiples of 4 and <= 4096, offsets 16-byte aligned: one workgroup each
+__global__ __launch_bounds__(256) void fill_segments_kernel(float* base, const int64_t* segs, float v) {
+    const int64_t off = segs[2 * blockIdx.x], len = segs[2 * blockIdx.x + 1];
+    const float4 v4 = make_float4(v, v, v, v);
+    for (int64_t i = 4 * (int64_t)threadIdx.x; i < len; i += 1024) *reinterpret_cast<float4*>(base + off + i) = v4;
+}
 static inline int ogrid(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -146,6 +152,11 @@ extern "C" int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t
 extern "C" int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     return launch_status("cast_bf16");
+}
+extern "C" int mdm_fill_segments_f32(float* base, const int64_t* segs, int nseg, float v, void* stream) {
+    MDM_REQUIRE(base && segs && nseg > 0, "fill_segments: bad arguments");
+    hipLaunchKernelGGL(fill_segments_kernel, dim3((unsigned)nseg), dim3(256), 0, (hipStream_t)stream, base, segs, v);
+    return launch_status("fill_segments");
 }
 extern "C" int mdm_fill_f32(float* p, float v, int64_t n, void* stream) {
     hipLaunchKernelGGL(fill_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);

@@ -92,6 +92,7 @@ _PROTOS = {
     "mdm_transpose_shadow": ([vp, vp, vp, i32, vp], i32),
     "mdm_transpose_shadow_bf16": ([vp, vp, vp, i32, vp], i32),
     "mdm_fill_f32": ([vp, f32, i64, vp], i32),
+    "mdm_fill_segments_f32": ([vp, vp, i32, f32, vp], i32),
     "mdm_graph_begin": ([vp], i32),
     "mdm_graph_end": ([vp, C.POINTER(vp)], i32),
     "mdm_graph_launch": ([vp, vp], i32),

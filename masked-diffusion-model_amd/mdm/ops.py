@@ -277,5 +277,10 @@ def fill(t, v):
     call("mdm_fill_f32", ptr(t), float(v), t.numel(), stream())
 
 
+def fill_segments(t, segs, v=0.0):
+    """t[off:off+len] = v for the (off, len) rows of the device int64 table `segs`."""
+    call("mdm_fill_segments_f32", ptr(t), ptr(segs), int(segs.shape[0]), float(v), stream())
+
+
 def cast_bf16(src, dst):
     call("mdm_cast_bf16", ptr(src), ptr(dst), src.numel(), stream())

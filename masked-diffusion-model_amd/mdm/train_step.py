@@ -164,7 +164,7 @@ class TrainStep:
         else:
             Cm = S._check_degrade_args(self.x0)
         self._emit_forward_loss(None, None, mask_in, Cm, self.wtab_dev is not None)
-        ops.fill(m.store.G, 0.0)
+        m.emit_zero_grad()
 
     def _build_graphs(self):
         """front = draws + degrade + shift + forward + loss; the backward is cut at every grouped weight-gradient launch

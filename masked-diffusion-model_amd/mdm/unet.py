@@ -228,6 +228,7 @@ class _Conv:
         grouped = n.dt == BF16 and n.group_wgrads and _lib.wgrad_group_accepts(**wf)
         if grouped:
             wf["acc0"] = 0
+            n.overwritten.add(self.name + ".weight")     # this slot of G is stored, not accumulated: no zeroing needed
             wf["splitk"] = sk = ops.wgrad_group_split(g)
             if sk > 1:
                 wf["ws"] = n.wgrad_slab(sk * g.taps * g.Cout * g.Cin)
@@ -417,13 +418,15 @@ class _Temb:
         if self._skinny():      # 6 launches: bias gradients ride on the weight gradients, silu' on the data gradients
             splits = max(s_ for s_ in range(1, 17) if (ft // 64) % s_ == 0)
             slabs = f(splits, N, te)
-            ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1, dbias=n.fc_gb)
+            # single writers of their weight-gradient slots: stored (acc=0), so those slots need no zeroing either
+            n.overwritten.update(n.fc_weight_names + [self.l1 + ".weight", self.l2 + ".weight"])
+            ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=0, out_f32=1, dbias=n.fc_gb)
             ops.skinny_linear_bwd(n.dT_all, n.fc_w, N, te, ft, dx=d_tm, pre=self.tm, splits=splits, slabs=slabs)
             if splits > 1:
                 ops.silu_bwd_sum(self.tm, slabs, splits, N * te, d_tm)
-            ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g(self.l2 + ".weight"), te, acc=1, out_f32=1, dbias=st.g(self.l2 + ".bias"))
+            ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g(self.l2 + ".weight"), te, acc=0, out_f32=1, dbias=st.g(self.l2 + ".bias"))
             ops.skinny_linear_bwd(d_tm, st.f(self.l2 + ".weight"), N, te, te, dx=d_h1, pre=self.h1)
-            ops.matmul(F32, 2, te, hid, N, d_h1, te, self.e, hid, st.g(self.l1 + ".weight"), hid, acc=1, out_f32=1, dbias=st.g(self.l1 + ".bias"))
+            ops.matmul(F32, 2, te, hid, N, d_h1, te, self.e, hid, st.g(self.l1 + ".weight"), hid, acc=0, out_f32=1, dbias=st.g(self.l1 + ".bias"))
             return
         ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1)
         ops.colsum(F32, n.dT_all, 1, N, ft, dbias=n.fc_gb)
@@ -484,7 +487,9 @@ class UNet:
                 params = self._default_params(seed)
             self.load_state_dict(params)
         self.forward_plan = self._record(self._emit_fwd)
+        self.overwritten = set()         # gradient slots the backward STORES (filled in while it is recorded)
         self.backward_plan = self._record(self._emit_bwd)
+        self._build_zero_table()
         self._graph_fwd = None
 
     def _default_params(self, seed):
@@ -715,6 +720,7 @@ class UNet:
         assert all(co % 8 == 0 for _, co in self.fc_slots.values())
         self.fc_w, self.fc_gw = st.P[e0.off:e0.off + ft * te].view(ft, te), st.G[e0.off:e0.off + ft * te].view(ft, te)
         self.fc_b, self.fc_gb = st.P[e1.off:e1.off + ft], st.G[e1.off:e1.off + ft]
+        self.fc_weight_names = [nm + ".weight" for nm in names]
         self.T_all = self.alloc((self.N, ft), torch.float32)
         self.dT_all = self.alloc((self.N, ft), torch.float32)
         self.t_in = self.alloc((self.N,), torch.float32)
@@ -832,6 +838,27 @@ class UNet:
 
     def zero_grad(self):
         self.store.G.zero_()
+
+    def _build_zero_table(self):
+        """(offset, length) pieces of G that the recorded backward ACCUMULATES into (atomics / += : biases, GroupNorm scales,
+        any weight gradient that is not a single stored launch): what `emit_zero_grad` clears before a step.  The slots in
+        `overwritten` are written whole by exactly one launch per step."""
+        rows = []
+        for name, e in self.store.entries.items():
+            if name in self.overwritten:
+                continue
+            size = (e.n + 7) // 8 * 8
+            for o in range(0, size, 4096):
+                rows.append((e.off + o, min(4096, size - o)))
+        self.zero_table = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None
+        self.zero_floats = sum(r[1] for r in rows)
+
+    def emit_zero_grad(self):
+        """Clear the accumulated gradient slots (launch, recordable): the per-step `optimizer.zero_grad()`."""
+        if self.zero_table is None or self.zero_floats * 2 > self.store.size:
+            ops.fill(self.store.G, 0.0)
+        else:
+            ops.fill_segments(self.store.G, self.zero_table, 0.0)
 
     def run_forward(self):
         """x_in (NHWC, padded) and t_in must already hold the inputs."""

@@ -143,3 +143,35 @@ def test_cfg5_250_step_bf16_sampler_on_the_preset():
     torch.cuda.synchronize()
     assert tuple(x0.shape) == (8, 3, 32, 32) and hist == []
     assert bool(torch.isfinite(x0).all()) and float(x0.abs().max()) < 50.0
+
+
+def test_sparse_gradient_zeroing_leaves_no_stale_gradient():
+    """The train step clears only the gradient slots the backward ACCUMULATES into (`UNet.emit_zero_grad`: biases, GroupNorm
+    scales) -- the grouped weight gradients and the time-embedding weight gradients STORE theirs.  Fill G with garbage, clear
+    it that way, run the recorded backward: every gradient must equal the one computed over a fully zeroed G."""
+    from mdm import ops
+    from mdm import unet as U
+    cfg, p, x, t, gy, yo, want = _case(4)
+    net = U.UNet(cfg, N=4, H=32, W=32, dtype=1, params=p, use_graph=False)
+    assert net.zero_table is not None and 0 < net.zero_floats < 0.02 * net.store.size, (net.zero_floats, net.store.size)
+    net.x_nchw.copy_(x)
+    net.t_in.copy_(t)
+    ops.nchw_to_nhwc(1, net.x_nchw, net.x_in.data, 4, 3, 32, 32, net.cin_p)
+
+    def grads(clear):
+        ops.nchw_to_nhwc(1, gy.to(net.device), net.y_out.grad, 4, 3, 32, 32, net.cout_p)
+        net.forward_plan.run()
+        clear()
+        net.backward_plan.run()
+        torch.cuda.synchronize()
+        return net.store.G.clone()
+
+    ref = grads(net.zero_grad)
+
+    def garbage_then_sparse():
+        net.store.G.fill_(123.0)
+        net.emit_zero_grad()
+    got = grads(garbage_then_sparse)
+    assert bool(torch.isfinite(got).all())
+    assert _rel(got, ref) < 1e-5, _rel(got, ref)                 # float atomics reorder the accumulated slots only
+    assert float((got - ref).abs().max()) < 1e-3 * float(ref.abs().max())
