@@ -182,7 +182,9 @@ int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1,
                           int N, int P, int G, const float* gamma, const float* beta, int silu,
                           const void* dy, const float* stats, void* dst0, const void* add0, void* dst1, const void* add1,
                           float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all, float* ws,
-                          void* stream);
+                          const void* add0b, void* stream);
+/* add0b (NULL = none): a SECOND tensor laid out like dst0 that is added too -- an activation with two forward consumers and a
+ * residual join receives dst0 (accumulate) + the residual branch's dY + dx in one pass. */
 
 /* ------------------------------------------------------------------------- *
  * Fused single-head attention of AttentionBlock.qkv (unet6.py:316-324): o = softmax(q k^T * scale) v over L tokens,

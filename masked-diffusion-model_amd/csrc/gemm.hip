@@ -1286,8 +1286,13 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     {
         bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
         float8 v = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-        if (d.acc0 || d.gnb_add) {         // accumulate in place, or add a tensor laid out like D0 (the residual branch's gradient)
-            const float8 old = load8(d.acc0 ? p : reinterpret_cast<const bf16_t*>(d.gnb_add) + (int64_t)m * d.ldd0 + n);
+        if (d.acc0) {                      // accumulate in place
+            const float8 old = load8(p);
+            v.lo.x += old.lo.x; v.lo.y += old.lo.y; v.lo.z += old.lo.z; v.lo.w += old.lo.w;
+            v.hi.x += old.hi.x; v.hi.y += old.hi.y; v.hi.z += old.hi.z; v.hi.w += old.hi.w;
+        }
+        if (d.gnb_add) {                   // and / or add a tensor laid out like D0 (the residual branch's gradient)
+            const float8 old = load8(reinterpret_cast<const bf16_t*>(d.gnb_add) + (int64_t)m * d.ldd0 + n);
             v.lo.x += old.lo.x; v.lo.y += old.lo.y; v.lo.z += old.lo.z; v.lo.w += old.lo.w;
             v.hi.x += old.hi.x; v.hi.y += old.hi.y; v.hi.z += old.hi.z; v.hi.w += old.hi.w;
         }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
                                                      const float* gamma, const float* beta, int silu, const T* dy,
-                                                     const float* stats, T* d0, const T* add0, T* d1, const T* add1,
+                                                     const float* stats, T* d0, const T* add0, T* d1, const T* add1, const T* add0b,
                                                      float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
     const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
     const float inv_cpg = rcp_small(cpg);
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
     if (on) {
         T* dst; const T* addp; int cc, CS;           // addp: a tensor laid out like dst whose values are added (dst itself = accumulate)
         if (c < C0) { dst = d0; addp = add0; cc = c; CS = C0; } else { dst = d1; addp = add1; cc = c - C0; CS = C1; }
+        const T* addq = c < C0 ? add0b : nullptr;    // a second addend for source 0 (accumulate AND a residual-branch gradient)
         float sx[8] = {};                     // column sums of dx (bias / time-embedding gradient of the producer conv)
         auto put = [&](int p, const float8& x, const float8& d) {
             float xv[8] = F8_TO_ARR(x);
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
                 float ov[8] = F8_TO_ARR(old);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] += ov[e];
+            }
+            if (addq) {
+                float8 old2 = load8(addq + (base + p) * CS + cc);
+                float ov2[8] = F8_TO_ARR(old2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += ov2[e];
             }
             float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
             store8(q, r);
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
 template <int NP, int MODE, int NT = 256>
 __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
                                                          const float* gamma, const float* beta, int silu, const bf16_t* dy,
-                                                         const float* stats, bf16_t* d0, const bf16_t* add0, bf16_t* d1, const bf16_t* add1,
+                                                         const float* stats, bf16_t* d0, const bf16_t* add0, bf16_t* d1, const bf16_t* add1, const bf16_t* add0b,
                                                          float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all,
                                                          float* ws) {
     constexpr int CS_PITCH = NT + 4;
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
     if (on) {
         bf16_t* dst; const bf16_t* addp; int cc, CS;
         if (c < C0) { dst = d0; addp = add0; cc = c; CS = C0; } else { dst = d1; addp = add1; cc = c - C0; CS = C1; }
+        const bf16_t* addq = c < C0 ? add0b : nullptr;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             int p = pbeg + lane + i * PL;
@@ -553,6 +561,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
                     float ov[8] = F8_TO_ARR(old);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += ov[e];
+                }
+                if (addq) {
+                    float8 old2 = load8(addq + (base + p) * CS + cc);
+                    float ov2[8] = F8_TO_ARR(old2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += ov2[e];
                 }
                 float8 r = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
                 store8(q, r);
@@ -804,7 +818,7 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
 extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                      const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                      void* dst0, const void* add0, void* dst1, const void* add1, float* dgamma, float* dbeta,
-                                     float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream) {
+                                     float* sum_img, int sum_ld, float* sum_all, float* ws, const void* add0b, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
     const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
@@ -814,7 +828,7 @@ extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const 
     if (dtype == MDM_BF16 && np <= 16) {
 #define GN_BWD_REG(NPV, NT) hipLaunchKernelGGL((gn_bwd_reg_kernel<NPV, 0, NT>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
                                                (const bf16_t*)src1, C1, P, G, cblk, gamma, beta, silu, (const bf16_t*)dy, stats,            \
-                                               (bf16_t*)dst0, (const bf16_t*)add0, (bf16_t*)dst1, (const bf16_t*)add1, dgamma, dbeta,       \
+                                               (bf16_t*)dst0, (const bf16_t*)add0, (bf16_t*)dst1, (const bf16_t*)add1, (const bf16_t*)add0b, dgamma, dbeta, \
                                                sum_img, sum_ld, sum_all, ws)
         if (np <= 1) GN_BWD_REG(1, 256); else if (np <= 2) GN_BWD_REG(2, 256); else if (np <= 4) GN_BWD_REG(2, 512);
         else if (np <= 8) GN_BWD_REG(4, 512); else GN_BWD_REG(8, 512);
@@ -823,7 +837,7 @@ extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const 
     }
     DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
                                          (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0,
-                                         (const T*)add0, (T*)dst1, (const T*)add1, dgamma, dbeta, sum_img, sum_ld, sum_all));
+                                         (const T*)add0, (T*)dst1, (const T*)add1, (const T*)add0b, dgamma, dbeta, sum_img, sum_ld, sum_all));
     return launch_status("groupnorm_bwd");
 }
 
@@ -833,7 +847,7 @@ extern "C" int mdm_groupnorm_bwd_sums(int dtype, const void* src0, int C0, const
                                       float* sum_img, int sum_ld, float* sum_all, float* ws, void* stream) {
     MDM_REQUIRE(!(sum_img || sum_all) || acc0 == 0, "groupnorm_bwd_sums: column sums need a plain (non-accumulating) dx");
     return mdm_groupnorm_bwd_add(dtype, src0, C0, src1, C1, N, P, G, gamma, beta, silu, dy, stats, dst0, acc0 ? dst0 : nullptr,
-                                 dst1, acc1 ? dst1 : nullptr, dgamma, dbeta, sum_img, sum_ld, sum_all, ws, stream);
+                                 dst1, acc1 ? dst1 : nullptr, dgamma, dbeta, sum_img, sum_ld, sum_all, ws, nullptr, stream);
 }
 
 extern "C" int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,

@@ -198,10 +198,12 @@ def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, ds
     """dst = (acc ? dst : add or 0) + dx.  add0 / add1: tensors laid out like dst0 / dst1 that are added without being
     modified (the gradient arriving over a residual branch)."""
     a0 = dst0 if acc0 else add0
+    a0b = add0 if acc0 else None            # accumulate AND a pending addend: both are added
+    assert not (acc1 and add1 is not None), "groupnorm_bwd: the second source takes one addend"
     a1 = dst1 if acc1 else add1
     call("mdm_groupnorm_bwd_add", dt, ptr(src0), C0, ptr(src1), C1, N, P, G, ptr(gamma), ptr(beta), int(silu), ptr(dy),
          ptr(stats), ptr(dst0), ptr(a0), ptr(dst1), ptr(a1), ptr(dgamma), ptr(dbeta), ptr(sum_img), sum_ld,
-         ptr(sum_all), ptr(ws), stream())
+         ptr(sum_all), ptr(ws), ptr(a0b), stream())
 
 
 def attn_supported(dt, L, C):

@@ -238,7 +238,7 @@ class _Conv:
             ops.conv_wgrad(n.dt, g, dy, s0.data, s1.data if s1 else None, st.g(self.name + ".weight"), ws=n.splitk_ws,
                            dbias=st.g(self.name + ".bias") if fuse_bias else None)
         if r is not None and r.needs_grad:       # y = conv(..) + resid  (unet6.py:333, 362): d(resid) += dy
-            if r.grad_written:
+            if r.grad_written and not (grouped and r.pending_add is None):
                 ops.add_(n.dt, r.grad, dy)
             elif grouped:
                 r.pending_add = dy               # folded in by the next writer of r.grad (dst = dy + dx): dy stays intact
@@ -258,7 +258,7 @@ class _Conv:
             # 4x4 / 8x8 maps: the data gradient runs on whole-image tiles, so the GroupNorm backward is its epilogue --
             # d(z) never goes to memory and the GroupNorm launch disappears (_Norm.bwd sees bwd_fused)
             x = nm.src0
-            gx, ax, addx = n.grad_for_write(x, want_add=True)
+            gx, ax, addx = n.grad_for_write(x, want_add=2)
             sums = {}
             prod = getattr(nm, "producer", None)     # conv1 of a ResidualBlock: this dx is its complete dY
             if prod is not None and ax == 0 and addx is None:
@@ -312,7 +312,7 @@ class _Norm:
         if getattr(self, "bwd_fused", False):       # done in the epilogue of the consuming conv's data gradient
             return
         dyo = n.grad_for_read(self.out)
-        g0, a0, add0 = n.grad_for_write(s0, want_add=True)
+        g0, a0, add0 = n.grad_for_write(s0, want_add=2)
         g1, a1, add1 = n.grad_for_write(s1, want_add=True) if s1 is not None else (None, 0, None)
         sums = {}
         prod = getattr(self, "producer", None)      # conv1 of a ResidualBlock: this dx is its complete dY
@@ -662,16 +662,17 @@ class UNet:
         return self._scratch
 
     def grad_for_write(self, act, want_add=False):
-        """-> (grad tensor, acc, add): the caller writes grad = (acc ? grad : add or 0) + its contribution.  `add` is a
+        """-> (grad tensor, acc, add): the caller writes grad = (acc ? grad : 0) + (add or 0) + its contribution.  `add` is a
         pending contribution (the untouched dy of a residual join, see _Conv.bwd); only callers that can add a second
-        tensor ask for it (want_add), for the others it is folded in by a separate launch first."""
+        tensor ask for it (want_add: 1 = instead of an accumulate, 2 = also next to one), for the others it is folded in
+        by a separate launch first."""
         if act.grad is None:
             act.grad = self.alloc((act.N, act.H, act.W, act.C), self.tdtype)
         add = None
         if act.pending_add is not None:
             pend, act.pending_add = act.pending_add, None
-            if want_add and not act.grad_written:
-                add = pend
+            if want_add == 2 or (want_add and not act.grad_written):
+                add = pend                  # want_add == 2: the caller can add it NEXT TO an accumulate (two addends)
             else:
                 ops.add3(self.dt, act.grad, pend, act.grad if act.grad_written else None)
                 act.grad_written = True
