@@ -1188,17 +1188,18 @@ __device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, float
 
 // ----------------------------------------------------------------------------
 // GroupNorm backward fused into the data-gradient epilogue of the conv that consumes the normalised tensor, for the
-// 64-pixel x 64-channel halo tiles of whole images (4x4 / 8x8 maps): the tile IS complete (image, group) blocks, so the
-// group sums stay inside the workgroup and d(z) never goes to memory.  512 threads = 64 pixels x 8 channel chunks.
-// Same arithmetic as gn_bwd_reg_kernel (norm.hip); d(z) enters in fp32 instead of bf16.
-// LDS: [0, 16K) the fp32 tile, [16K, 80K) column-sum scratch, then small arrays.
+// 64-pixel x BN-channel halo tiles of whole images (4x4 / 8x8 maps; BN = 64 or 32): the tile IS complete (image, group)
+// blocks, so the group sums stay inside the workgroup and d(z) never goes to memory.  64 pixels x NCH = BN / 8 channel
+// chunks = 512 or 256 active threads.  Same arithmetic as gn_bwd_reg_kernel (norm.hip); d(z) enters in fp32 instead of bf16.
+// LDS: [0, 16K) the fp32 tile, [16K, 80K) column-sum scratch [32 quantities][512], then small arrays.
 // ----------------------------------------------------------------------------
-template <int MI, int NI>
+template <int MI, int NI, int BN>
 __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
                                                   int lane, int t, f32x4 (&acc)[MI][NI]) {
-    constexpr int BM = 64, BN = 64, PITCH = BN * 4;
+    constexpr int PITCH = BN * 4, NCH = BN / 8, NCH_SH = NCH == 8 ? 3 : 2, ACTIVE = 64 * NCH;
+    static_assert(BN == 64 || BN == 32, "fused GroupNorm epilogues: 64- or 32-channel tiles");
     float* scratch = reinterpret_cast<float*>(lds + 16384);               // [32][512]
-    float* psum = reinterpret_cast<float*>(lds + 16384 + 65536);          // [256 columns][4 parts]
+    float* psum = reinterpret_cast<float*>(lds + 16384 + 65536);          // [32 NCH columns][4 parts]
     float* gs = psum + 1024;                                              // [4 images][16 groups][2]
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -1212,78 +1213,80 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     }
     if (t < 128) gs[t] = 0.f;
     __syncthreads();
-    // P = 16 or 64 pixels per image, cpg = 4 .. 64 channels per group: powers of two (mdm_gemm_can_fuse_gn_bwd), so the
+    // P = 16 or 64 pixels per image, cpg = 4 .. BN channels per group: powers of two (mdm_gemm_can_fuse_gn_bwd), so the
     // per-element group index is a shift (it was 16 integer divisions per thread)
     const int C = d.N, G = d.gnb_G, P = d.OH * d.OW, p_sh = __builtin_ctz(P), cpg_sh = __builtin_ctz(C) - __builtin_ctz(G), cpg = 1 << cpg_sh;
-    const int r = t >> 3, q = t & 7, il = r >> p_sh;
+    const bool on = t < ACTIVE;
+    const int r = (t >> NCH_SH) & 63, q = t & (NCH - 1), il = r >> p_sh;
     const int m = m0 + r, n = n0 + q * 8, img = (m0 >> p_sh) + il;
-    const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
-    const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
-    const float dz[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const float8 x8 = load8(reinterpret_cast<const bf16_t*>(d.gnb_x) + (int64_t)m * C + n);
-    const float xv[8] = {x8.lo.x, x8.lo.y, x8.lo.z, x8.lo.w, x8.hi.x, x8.hi.y, x8.hi.z, x8.hi.w};
-    const float4 g_lo = *reinterpret_cast<const float4*>(d.gnb_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnb_gamma + n + 4);
-    const float4 b_lo = *reinterpret_cast<const float4*>(d.gnb_beta + n), b_hi = *reinterpret_cast<const float4*>(d.gnb_beta + n + 4);
-    const float ga[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
-    const float be[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
-    float rstd[8], xh[8], gz[8];
+    float rstd[8], xh[8], gz[8], ga[8];
+    if (on) {
+        const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
+        const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
+        const float dz[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float8 x8 = load8(reinterpret_cast<const bf16_t*>(d.gnb_x) + (int64_t)m * C + n);
+        const float xv[8] = {x8.lo.x, x8.lo.y, x8.lo.z, x8.lo.w, x8.hi.x, x8.hi.y, x8.hi.z, x8.hi.w};
+        const float4 g_lo = *reinterpret_cast<const float4*>(d.gnb_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnb_gamma + n + 4);
+        const float4 b_lo = *reinterpret_cast<const float4*>(d.gnb_beta + n), b_hi = *reinterpret_cast<const float4*>(d.gnb_beta + n + 4);
+        const float gav[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
+        const float be[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + ((n + e) >> cpg_sh)) * 2);
-        rstd[e] = st.y;
-        xh[e] = (xv[e] - st.x) * st.y;
-        gz[e] = dz[e];
-        if (d.gnb_silu) gz[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
-        scratch[e * 512 + t] = gz[e] * ga[e];                             // a1: sum over the group of dy*gamma
-        scratch[(8 + e) * 512 + t] = gz[e] * ga[e] * xh[e];               // a2
-        scratch[(16 + e) * 512 + t] = gz[e] * xh[e];                      // dgamma
-        scratch[(24 + e) * 512 + t] = gz[e];                              // dbeta
+        for (int e = 0; e < 8; ++e) {
+            const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + ((n + e) >> cpg_sh)) * 2);
+            ga[e] = gav[e];
+            rstd[e] = st.y;
+            xh[e] = (xv[e] - st.x) * st.y;
+            gz[e] = dz[e];
+            if (d.gnb_silu) gz[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
+            scratch[e * 512 + t] = gz[e] * ga[e];                             // a1: sum over the group of dy*gamma
+            scratch[(8 + e) * 512 + t] = gz[e] * ga[e] * xh[e];               // a2
+            scratch[(16 + e) * 512 + t] = gz[e] * xh[e];                      // dgamma
+            scratch[(24 + e) * 512 + t] = gz[e];                              // dbeta
+        }
     }
     __syncthreads();
-    // column sums over the pixels, in 4 parts of 16 rows (a part never straddles an image: P is 16 or 64)
+    // column sums over the pixels, in 4 parts of 16 rows (a part never straddles an image: P is 16 or 64);
+    // column = quantity k (0..31) x chunk: the values of one column sit NCH words apart in row k of the scratch
 #pragma unroll
-    for (int it2 = 0; it2 < 2; ++it2) {
-        const int id = t + 512 * it2, col = id >> 2, part = id & 3;      // col = k * 8 + chunk
-        const float* src = scratch + (col >> 3) * 512 + (part * 16) * 8 + (col & 7);
+    for (int it2 = 0; it2 < (32 * NCH * 4) / 512; ++it2) {
+        const int id = t + 512 * it2, col = id >> 2, part = id & 3;       // col = k * NCH + chunk
+        const float* src = scratch + (col >> NCH_SH) * 512 + (part * 16) * NCH + (col & (NCH - 1));
         float sum = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) sum += src[rr * 8];
+        for (int rr = 0; rr < 16; ++rr) sum += src[rr * NCH];
         psum[id] = sum;
     }
     __syncthreads();
-    if (t < 128) {                       // dgamma / dbeta: one atomic per channel per workgroup
-        const int which = t >> 6, c = t & 63, col = ((16 + 8 * which + (c & 7)) << 3) + (c >> 3);
+    if (t < 2 * BN) {                    // dgamma / dbeta: one atomic per channel per workgroup
+        const int which = t >= BN ? 1 : 0, c = t - which * BN, col = (16 + 8 * which + (c & 7)) * NCH + (c >> 3);
         const float v = psum[col * 4] + psum[col * 4 + 1] + psum[col * 4 + 2] + psum[col * 4 + 3];
         atomicAdd(which ? d.gnb_dbeta + n0 + c : d.gnb_dgamma + n0 + c, v);
     }
-    {                                    // group sums per image: (image il2, channel c) -> gs[il2][group][0/1]
-        const int ppi = P >> 4;          // parts per image (1 or 4)
-        const int nimg = 64 >> p_sh;
-        if (t < nimg * 64) {
-            const int il2 = t >> 6, c = t & 63;
+    const int ppi = P >> 4, nimg = 64 >> p_sh;          // parts per image (1 or 4), images per tile
+    if (t < nimg * BN) {                 // group sums per image: (image il2, channel c) -> gs[il2][group][0/1]
+        const int il2 = t / BN, c = t - il2 * BN;
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const int col = ((8 * w + (c & 7)) << 3) + (c >> 3);
-                float v = 0.f;
-                for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
-                atomicAdd(&gs[(il2 * 16 + (c >> cpg_sh)) * 2 + w], v);
-            }
+        for (int w = 0; w < 2; ++w) {
+            const int col = (8 * w + (c & 7)) * NCH + (c >> 3);
+            float v = 0.f;
+            for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
+            atomicAdd(&gs[(il2 * 16 + (c >> cpg_sh)) * 2 + w], v);
         }
     }
     __syncthreads();
     const float inv_cnt = 1.f / ((float)cpg * (float)P);
     float o[8];
+    if (on) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int gl = (q * 8 + e) >> cpg_sh;
-        const float k1 = rstd[e] * gs[(il * 16 + gl) * 2] * inv_cnt, k2 = rstd[e] * gs[(il * 16 + gl) * 2 + 1] * inv_cnt;
-        o[e] = rstd[e] * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
-    }
-    if (d.gnb_sum_img || d.gnb_sum_all) {                                  // uniform: column sums of dx (before accumulation)
+        for (int e = 0; e < 8; ++e) {
+            const int gl = (q * 8 + e) >> cpg_sh;
+            const float k1 = rstd[e] * gs[(il * 16 + gl) * 2] * inv_cnt, k2 = rstd[e] * gs[(il * 16 + gl) * 2 + 1] * inv_cnt;
+            o[e] = rstd[e] * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
+        }
+        if (d.gnb_sum_img || d.gnb_sum_all) {                                  // uniform: column sums of dx (before accumulation)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) scratch[e * 512 + t] = o[e];
-    }
-    {
+            for (int e = 0; e < 8; ++e) scratch[e * 512 + t] = o[e];
+        }
         bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
         float8 v = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
         if (d.acc0) {                      // accumulate in place
@@ -1300,18 +1303,17 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
     }
     if (d.gnb_sum_img || d.gnb_sum_all) {
         __syncthreads();
-        if (t < 256) {
-            const int col = t >> 2, part = t & 3;                          // col = e * 8 + chunk
-            const float* src = scratch + (col >> 3) * 512 + (part * 16) * 8 + (col & 7);
+        if (t < 8 * NCH * 4) {
+            const int col = t >> 2, part = t & 3;                          // col = e * NCH + chunk
+            const float* src = scratch + (col >> NCH_SH) * 512 + (part * 16) * NCH + (col & (NCH - 1));
             float sum = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) sum += src[rr * 8];
+            for (int rr = 0; rr < 16; ++rr) sum += src[rr * NCH];
             psum[t] = sum;
         }
         __syncthreads();
-        const int ppi = P >> 4, nimg = 64 >> p_sh;
-        if (t < nimg * 64) {
-            const int il2 = t >> 6, c = t & 63, col = ((c & 7) << 3) + (c >> 3);
+        if (t < nimg * BN) {
+            const int il2 = t / BN, c = t - il2 * BN, col = (c & 7) * NCH + (c >> 3);
             float v = 0.f;
             for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
             if (d.gnb_sum_img) d.gnb_sum_img[(int64_t)((m0 >> p_sh) + il2) * d.gnb_sum_ld + n0 + c] = v;      // this workgroup owns (image, channel)
@@ -1322,17 +1324,18 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
 
 
 // ----------------------------------------------------------------------------
-// GroupNorm forward fused into the epilogue of the conv that PRODUCES the tensor (same 64-pixel x 64-channel tiles of
+// GroupNorm forward fused into the epilogue of the conv that PRODUCES the tensor (same 64-pixel x BN-channel tiles of
 // whole images): the usual epilogue (scale, bias, time-embedding row, residual, bf16 rounding, store y), then
 // statistics over the ROUNDED values exactly as a separate GroupNorm launch would see them -- two passes (mean, then
 // centred squares: exact for constant maps like the pivot-shifted sums of norm.hip) -- and z = silu?(y_hat*gamma+beta).
 // ----------------------------------------------------------------------------
-template <int MI, int NI>
+template <int MI, int NI, int BN>
 __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
                                                   int lane, int t, f32x4 (&acc)[MI][NI]) {
-    constexpr int BN = 64, PITCH = BN * 4;
+    constexpr int PITCH = BN * 4, NCH = BN / 8, NCH_SH = NCH == 8 ? 3 : 2, ACTIVE = 64 * NCH;
+    static_assert(BN == 64 || BN == 32, "fused GroupNorm epilogues: 64- or 32-channel tiles");
     float* scratch = reinterpret_cast<float*>(lds + 16384);               // [8][512]
-    float* psum = reinterpret_cast<float*>(lds + 16384 + 16384);          // [64 columns][4 parts]
+    float* psum = reinterpret_cast<float*>(lds + 16384 + 16384);          // [8 NCH columns][4 parts]
     float* gs = psum + 256;                                               // [4 images][16 groups]: sum, then centred squares
     float* gm = gs + 64;                                                  // mean
     float* gr = gm + 64;                                                  // rstd
@@ -1352,42 +1355,49 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
     if (t < 64) gs[t] = 0.f;
     __syncthreads();
     const int C = d.N, G = d.gnf_G, P = d.OH * d.OW, p_sh = __builtin_ctz(P), cpg_sh = __builtin_ctz(C) - __builtin_ctz(G), cpg = 1 << cpg_sh;
-    const int r = t >> 3, q = t & 7, il = r >> p_sh;             // powers of two (mdm_gemm_can_fuse_gn_fwd): shifts, not divisions
+    const bool on = t < ACTIVE;
+    const int r = (t >> NCH_SH) & 63, q = t & (NCH - 1), il = r >> p_sh;     // powers of two (mdm_gemm_can_fuse_gn_fwd): shifts, not divisions
     const int m = m0 + r, n = n0 + q * 8;
-    const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
-    const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
-    float8 v = {lo, hi};
-    if (d.resid) {
-        const float8 b = load8(reinterpret_cast<const bf16_t*>(d.resid) + (int64_t)m * d.ldr + n);
-        v.lo.x += b.lo.x; v.lo.y += b.lo.y; v.lo.z += b.lo.z; v.lo.w += b.lo.w;
-        v.hi.x += b.hi.x; v.hi.y += b.hi.y; v.hi.z += b.hi.z; v.hi.w += b.hi.w;
-    }
-    bf16_t* yp = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
-    store8(yp, v);
-    // the values as GroupNorm reads them back: rounded to bf16
-    const float vv[8] = {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w};
     float y[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = bf2f(f2bf(vv[e]));
+    for (int e = 0; e < 8; ++e) y[e] = 0.f;
+    if (on) {
+        const float4 lo = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q) ^ (r & 7)) << 4));
+        const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
+        float8 v = {lo, hi};
+        if (d.resid) {
+            const float8 b = load8(reinterpret_cast<const bf16_t*>(d.resid) + (int64_t)m * d.ldr + n);
+            v.lo.x += b.lo.x; v.lo.y += b.lo.y; v.lo.z += b.lo.z; v.lo.w += b.lo.w;
+            v.hi.x += b.hi.x; v.hi.y += b.hi.y; v.hi.z += b.hi.z; v.hi.w += b.hi.w;
+        }
+        bf16_t* yp = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
+        store8(yp, v);
+        // the values as GroupNorm reads them back: rounded to bf16
+        const float vv[8] = {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = bf2f(f2bf(vv[e]));
+    }
     const int ppi = P >> 4, nimg = 64 >> p_sh;
     const float inv_cnt = 1.f / ((float)cpg * (float)P);
     float mean[8], rstd[8];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+        if (on) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float c0 = pass ? y[e] - mean[e] : y[e]; scratch[e * 512 + t] = pass ? c0 * c0 : c0; }
+            for (int e = 0; e < 8; ++e) { const float c0 = pass ? y[e] - mean[e] : y[e]; scratch[e * 512 + t] = pass ? c0 * c0 : c0; }
+        }
         __syncthreads();
-        if (t < 256) {
-            const int col = t >> 2, part = t & 3;                          // col = e * 8 + chunk
-            const float* src = scratch + (col >> 3) * 512 + (part * 16) * 8 + (col & 7);
+        if (t < 8 * NCH * 4) {
+            const int col = t >> 2, part = t & 3;                          // col = e * NCH + chunk
+            const float* src = scratch + (col >> NCH_SH) * 512 + (part * 16) * NCH + (col & (NCH - 1));
             float sum = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) sum += src[rr * 8];
+            for (int rr = 0; rr < 16; ++rr) sum += src[rr * NCH];
             psum[t] = sum;
         }
         __syncthreads();
-        if (t < nimg * 64) {
-            const int il2 = t >> 6, c = t & 63, col = ((c & 7) << 3) + (c >> 3);
+        if (t < nimg * BN) {
+            const int il2 = t / BN, c = t - il2 * BN, col = (c & 7) * NCH + (c >> 3);
             float s2 = 0.f;
             for (int pp = 0; pp < ppi; ++pp) s2 += psum[col * 4 + il2 * ppi + pp];
             atomicAdd(&gs[il2 * 16 + (c >> cpg_sh)], s2);
@@ -1407,21 +1417,23 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
             for (int e = 0; e < 8; ++e) rstd[e] = gr[il * 16 + ((q * 8 + e) >> cpg_sh)];
         }
     }
-    const float4 g_lo = *reinterpret_cast<const float4*>(d.gnf_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnf_gamma + n + 4);
-    const float4 b_lo = *reinterpret_cast<const float4*>(d.gnf_beta + n), b_hi = *reinterpret_cast<const float4*>(d.gnf_beta + n + 4);
-    const float ga[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
-    const float be[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
-    float o[8];
+    if (on) {
+        const float4 g_lo = *reinterpret_cast<const float4*>(d.gnf_gamma + n), g_hi = *reinterpret_cast<const float4*>(d.gnf_gamma + n + 4);
+        const float4 b_lo = *reinterpret_cast<const float4*>(d.gnf_beta + n), b_hi = *reinterpret_cast<const float4*>(d.gnf_beta + n + 4);
+        const float ga[8] = {g_lo.x, g_lo.y, g_lo.z, g_lo.w, g_hi.x, g_hi.y, g_hi.z, g_hi.w};
+        const float be[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+        float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o[e] = fmaf((y[e] - mean[e]) * rstd[e], ga[e], be[e]);
-        if (d.gnf_silu) o[e] = silu_f(o[e]);
+        for (int e = 0; e < 8; ++e) {
+            o[e] = fmaf((y[e] - mean[e]) * rstd[e], ga[e], be[e]);
+            if (d.gnf_silu) o[e] = silu_f(o[e]);
+        }
+        const float8 zo = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+        store8(reinterpret_cast<bf16_t*>(d.gnf_out) + (int64_t)m * C + n, zo);
     }
-    const float8 zo = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-    store8(reinterpret_cast<bf16_t*>(d.gnf_out) + (int64_t)m * C + n, zo);
-    const int ngt = 64 >> cpg_sh;                                          // groups inside this 64-channel tile
+    const int ngt = BN >> cpg_sh;                                          // groups inside this BN-channel tile
     if (t < nimg * ngt) {
-        const int il2 = t >> (6 - cpg_sh), gl = t - il2 * ngt;
+        const int il2 = t / ngt, gl = t - il2 * ngt;
         float* sp = d.gnf_stats + ((int64_t)((m0 >> p_sh) + il2) * G + (n0 >> cpg_sh) + gl) * 2;
         sp[0] = gm[il2 * 16 + gl]; sp[1] = gr[il2 * 16 + gl];
     }
@@ -2145,9 +2157,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     wait_vmcnt<0>();
     MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
-    if constexpr (BM == 64 && BN == 64) {
-        if (d.gnb_x) epilogue_tile_gnb<MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
-        else if (d.gnf_out) epilogue_tile_gnf<MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+    if constexpr (BM == 64 && (BN == 64 || BN == 32)) {
+        if (d.gnb_x) epilogue_tile_gnb<MI, NI, BN>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
+        else if (d.gnf_out) epilogue_tile_gnf<MI, NI, BN>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
         else epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
         epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
@@ -2458,9 +2470,10 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 2>(d, s) : launch_halo<256, 6, 2>(d, s))
                  : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 2>(d, s) : npw <= 4 ? launch_halo<128, 4, 2>(d, s) : launch_halo<128, 6, 2>(d, s))
                  // whole-image 64-pixel tiles (4x4 / 8x8 maps): the loop is the filter stream of ONE workgroup (64 output
-                 // channels x 9 C x 2 B at ~27 B/clk), so without a fused GroupNorm epilogue (which needs whole groups of a
-                 // 64-channel tile) 32 output channels per workgroup halve it and double the workgroups
-                 : (!d.gnb_x && !d.gnf_out && d.N % 32 == 0)
+                 // channels x 9 C x 2 B) and these maps give only 32-128 such workgroups: 32 output channels per workgroup
+                 // halve the stream and double the workgroups.  A fused GroupNorm epilogue needs whole groups inside the
+                 // tile: groups of <= 32 channels
+                 : (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32))
                      ? (npw <= 2 ? launch_halo<64, 2, 3, 32>(d, s) : launch_halo<64, 3, 3, 32>(d, s))
                      : (npw <= 2 ? launch_halo<64, 2, 3>(d, s) : launch_halo<64, 3, 3>(d, s));
         } else if (big) {
