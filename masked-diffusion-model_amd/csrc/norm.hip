@@ -449,6 +449,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
     }
     const int64_t base = (int64_t)img * P;
     uint4 cx[NP], cd[NP];
+    // the tensors ADDED to dx (accumulated gradient / residual branch) are fetched with x and dy, not behind the reduction:
+    // a second exposed memory round trip on a kernel that is one round trip + a reduction long
+    constexpr bool PRE_ADD = NP <= 4;
+    uint4 cadd[PRE_ADD ? NP : 1], caddq[PRE_ADD ? NP : 1];
     // single-launch mode with a small slice: dy * silu'(..) is kept in fp32 registers for the apply pass instead of being
     // recomputed (exp + rcp per element: the large-map kernels are VALU-bound, 1 wave per SIMD)
     constexpr bool CACHE = MODE == 0 && NP <= 8;
@@ -465,6 +469,12 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
             bool ok = p < pend;
             cx[i] = ok ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
             cd[i] = ok ? *reinterpret_cast<const uint4*>(dy + (base + p) * C + c) : make_uint4(0, 0, 0, 0);
+            if (PRE_ADD) {
+                const bf16_t* ap = c < C0 ? add0 : add1;
+                const int cc2 = c < C0 ? c : c - C0, CS2 = c < C0 ? C0 : C1;
+                cadd[i] = (ok && ap) ? *reinterpret_cast<const uint4*>(ap + (base + p) * CS2 + cc2) : make_uint4(0, 0, 0, 0);
+                caddq[i] = (ok && add0b && c < C0) ? *reinterpret_cast<const uint4*>(add0b + (base + p) * C0 + c) : make_uint4(0, 0, 0, 0);
+            }
         }
         {
             const float4 g_lo = *reinterpret_cast<const float4*>(gamma + c), g_hi = *reinterpret_cast<const float4*>(gamma + c + 4);
@@ -557,13 +567,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
                 }
                 bf16_t* q = dst + (base + p) * CS + cc;
                 if (addp) {
-                    float8 old = load8(addp + (base + p) * CS + cc);
+                    float8 old = PRE_ADD ? unpack8(cadd[PRE_ADD ? i : 0]) : load8(addp + (base + p) * CS + cc);
                     float ov[8] = F8_TO_ARR(old);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += ov[e];
                 }
                 if (addq) {
-                    float8 old2 = load8(addq + (base + p) * CS + cc);
+                    float8 old2 = PRE_ADD ? unpack8(caddq[PRE_ADD ? i : 0]) : load8(addq + (base + p) * CS + cc);
                     float ov2[8] = F8_TO_ARR(old2);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] += ov2[e];
