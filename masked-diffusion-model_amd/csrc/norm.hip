@@ -796,7 +796,8 @@ static int gn_cblk(int C, int G, int N, int P) {
     int cpg = C / G, l = cpg;
     while (l % 8) l += cpg;            // lcm(cpg, 8)
     // 32 channels per workgroup; 16 on large maps (more workgroups pulling HBM: 12.3 -> 10.1 us forward,
-    // 21.0 -> 15.8 us backward on 32x32x128; slower on the small maps, where the launch floor dominates)
+    // 21.0 -> 15.8 us backward on 32x32x128; slower on the small maps, where the launch floor dominates;
+    // re-measured at the end of round 2 on the whole step: 8 channels 3.989, 16 channels 3.958, 32 channels 4.008 ms)
     int want = P > 256 ? 16 : 32;
     int cb = l;
     while (cb < want) cb += l;
