@@ -342,11 +342,9 @@ int mdm_sqnorm(const float* g, int64_t n, float* out, void* stream);
 int mdm_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow_bf16,
                   int64_t n, const float* hp, const float* sqnorm, float max_norm, float gmul, void* stream);
 int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
-/* Transposed bf16 shadow of the conv filters for the data-gradient pass: for every 32x32 tile listed in
- * `tiles` (device, int64 x5 per tile: element offset of one tap's [Cout][Cin] matrix, Cout, Cin, row0, col0)
- * write PT[off + c*Cout + r] = bf16(P[off + r*Cin + c]). */
-int mdm_transpose_shadow(const float* P, void* PT, const int64_t* tiles, int ntiles, void* stream);
-/* the same from the bf16 shadow Pb (element offsets identical): PT[off + c*Cout + r] = Pb[off + r*Cin + c] */
+/* Transposed bf16 shadow of the conv filters for the data-gradient pass, from the bf16 shadow Pb the optimizer kernel writes:
+ * for every 64x64 tile listed in `tiles` (device, int64 x5 per tile: element offset of one tap's [Cout][Cin] matrix, Cout,
+ * Cin, row0, col0; Cout % 8 == Cin % 8 == 0) write PT[off + c*Cout + r] = Pb[off + r*Cin + c]. */
 int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, int ntiles, void* stream);
 int mdm_fill_f32(float* p, float v, int64_t n, void* stream);
 /* base[off .. off + len) = v for nseg segments segs[i] = {off, len} (device, int64 pairs; len % 4 == 0, len <= 4096, off % 4 == 0):

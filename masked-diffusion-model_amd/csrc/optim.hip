@@ -61,45 +61,37 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
-// Transposed bf16 shadow of the conv filters: master fp32 [tap][Cout][Cin] -> bf16 [tap][Cin][Cout], so the
-// data-gradient contraction reads its weights k-contiguous like the forward does.  One workgroup per
-// 32x32 tile of one tap of one layer; `tiles` = {src offset of the tap matrix, Cout, Cin, row0, col0} x ntiles.
-__global__ __launch_bounds__(256) void transpose_shadow_kernel(const float* P, bf16_t* PT, const int64_t* tiles, int ntiles) {
-    __shared__ float tile[32][33];
-    const int64_t* e = tiles + (int64_t)blockIdx.x * 5;
-    const int64_t off = e[0];
-    const int Cout = (int)e[1], Cin = (int)e[2], r0 = (int)e[3], c0 = (int)e[4];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < Cout && c < Cin) ? P[off + (int64_t)r * Cin + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = c0 + ty + 8 * i, r = r0 + tx;                        // write PT[c][r]
-        if (c < Cin && r < Cout) PT[off + (int64_t)c * Cout + r] = f2bf(tile[tx][ty + 8 * i]);
-    }
-}
-
-// the same transposition from the bf16 shadow (already rounded by the optimizer kernel): a third less traffic
+// Transposed bf16 shadow of the conv filters: bf16 [tap][Cout][Cin] (written by the optimizer kernel) -> bf16 [tap][Cin][Cout],
+// so the data-gradient contraction reads its weights k-contiguous like the forward does.  One workgroup per 64 x 64 tile of
+// one tap of one layer, 16-byte loads and stores on both sides (Cout, Cin are multiples of 8);
+// `tiles` = {element offset of the tap matrix, Cout, Cin, row0, col0} x ntiles.
+// (The first version moved 2 bytes per lane on 32 x 32 tiles: 62 us for 143 MB; this one is bound by the bytes.)
 __global__ __launch_bounds__(256) void transpose_shadow_bf16_kernel(const bf16_t* Pb, bf16_t* PT, const int64_t* tiles, int ntiles) {
-    __shared__ bf16_t tile[32][34];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
     const int64_t* e = tiles + (int64_t)blockIdx.x * 5;
     const int64_t off = e[0];
     const int Cout = (int)e[1], Cin = (int)e[2], r0 = (int)e[3], c0 = (int)e[4];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < Cout && c < Cin) ? Pb[off + (int64_t)r * Cin + c] : (bf16_t)0;
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, row = q >> 3, cc = (q & 7) * 8;
+        const int r = r0 + row, c = c0 + cc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < Cout && c < Cin) v = *reinterpret_cast<const uint4*>(Pb + off + (int64_t)r * Cin + c);
+        *reinterpret_cast<uint4*>(&tile[row][cc]) = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = c0 + ty + 8 * i, r = r0 + tx;                        // write PT[c][r]
-        if (c < Cin && r < Cout) PT[off + (int64_t)c * Cout + r] = tile[tx][ty + 8 * i];
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, col = q >> 3, rr = (q & 7) * 8;
+        const int c = c0 + col, r = r0 + rr;
+        if (c < Cin && r < Cout) {                                   // Cout % 8 == 0: the 8 rows are inside or outside together
+            uint4 v;
+            v.x = (uint32_t)tile[rr + 0][col] | ((uint32_t)tile[rr + 1][col] << 16);
+            v.y = (uint32_t)tile[rr + 2][col] | ((uint32_t)tile[rr + 3][col] << 16);
+            v.z = (uint32_t)tile[rr + 4][col] | ((uint32_t)tile[rr + 5][col] << 16);
+            v.w = (uint32_t)tile[rr + 6][col] | ((uint32_t)tile[rr + 7][col] << 16);
+            *reinterpret_cast<uint4*>(PT + off + (int64_t)c * Cout + r) = v;
+        }
     }
 }
 
@@ -138,11 +130,6 @@ extern "C" int mdm_adamw_ema(float* p, const float* g, float* m, float* v, float
     hipLaunchKernelGGL(adamw_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)shadow_bf16, n, hp,
                        sqnorm, max_norm, gmul);
     return launch_status("adamw");
-}
-extern "C" int mdm_transpose_shadow(const float* P, void* PT, const int64_t* tiles, int ntiles, void* stream) {
-    MDM_REQUIRE(P && PT && tiles && ntiles > 0, "transpose_shadow: bad arguments");
-    hipLaunchKernelGGL(transpose_shadow_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, P, (bf16_t*)PT, tiles, ntiles);
-    return launch_status("transpose_shadow");
 }
 extern "C" int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, int ntiles, void* stream) {
     MDM_REQUIRE(Pb && PT && tiles && ntiles > 0, "transpose_shadow_bf16: bad arguments");

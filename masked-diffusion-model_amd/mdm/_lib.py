@@ -89,7 +89,6 @@ _PROTOS = {
     "mdm_sqnorm": ([vp, i64, vp, vp], i32),
     "mdm_adamw_ema": ([vp, vp, vp, vp, vp, vp, i64, vp, vp, f32, f32, vp], i32),
     "mdm_cast_bf16": ([vp, vp, i64, vp], i32),
-    "mdm_transpose_shadow": ([vp, vp, vp, i32, vp], i32),
     "mdm_transpose_shadow_bf16": ([vp, vp, vp, i32, vp], i32),
     "mdm_fill_f32": ([vp, f32, i64, vp], i32),
     "mdm_fill_segments_f32": ([vp, vp, i32, f32, vp], i32),

@@ -88,9 +88,10 @@ class ParamStore:
                 if e.kind not in ("conv", "convlin"):
                     continue
                 taps, co, ci = e.ishape
+                assert co % 8 == 0 and ci % 8 == 0
                 for tp in range(taps):
-                    for r0 in range(0, co, 32):
-                        for c0 in range(0, ci, 32):
+                    for r0 in range(0, co, 64):           # 64 x 64 tiles (mdm_transpose_shadow_bf16)
+                        for c0 in range(0, ci, 64):
                             rows.append((e.off + tp * co * ci, co, ci, r0, c0))
             self.tiles = torch.tensor(rows, dtype=torch.int64, device=device)
 
