@@ -487,7 +487,7 @@ def test_grouped_weight_gradients_match_self_contained_ones():
 
 
 @pytest.mark.parametrize("case", [(8, 8, 256, 256, True, False), (16, 4, 128, 256, True, True), (4, 8, 128, 64, False, False),
-                                  (8, 8, 512, 256, True, True)])
+                                  (8, 8, 512, 256, True, True), (4, 4, 2048, 64, True, False)])      # last: 64-channel groups -> 64-wide tiles
 def test_groupnorm_backward_fused_into_the_data_gradient(case):
     """4x4 / 8x8 maps: z = silu?(GroupNorm(x)) feeds a 3x3 conv; the conv's data gradient runs the GroupNorm backward in
     its epilogue (gnb_*): dx, dgamma, dbeta and the optional column sums against torch autograd."""
@@ -535,7 +535,8 @@ def test_groupnorm_backward_fused_into_the_data_gradient(case):
         assert float((tot.cpu() - gx.sum((0, 1, 2))).abs().max()) < _tol(dt, 0.5) * scale * N
 
 
-@pytest.mark.parametrize("case", [(8, 8, 128, 256, True), (16, 4, 256, 128, True), (4, 8, 64, 512, False)])
+@pytest.mark.parametrize("case", [(8, 8, 128, 256, True), (16, 4, 256, 128, True), (4, 8, 64, 512, False),
+                                  (4, 4, 64, 2048, True)])                                          # last: 64-channel groups -> 64-wide tiles
 def test_groupnorm_forward_fused_into_the_producing_conv(case):
     """4x4 / 8x8 maps: the conv's epilogue (bias + time-embedding row + residual, bf16 store) also writes
     silu?(GroupNorm(y)) and the (mean, rstd) statistics (gnf_*)."""
