@@ -261,10 +261,12 @@ int mdm_nhwc_to_nchw(int dtype, const void* x, float* y, int N, int C, int H, in
  * ------------------------------------------------------------------------- */
 /* On-device draw of the per-sample step (trainer_masked_mean_shift.py:109-112,
  * scheduler.py:88-100, 780-794): idx ~ U{0..n_used-1}; t = used[idx]; amount = table[t-1];
- * weight = wtab[idx] (or 1).  Philox4x32-10 keyed by rng[0]=seed, rng[1]=offset (device memory). */
+ * weight = wtab[idx] (or 1); out2 = table2[t-1] for a second schedule table (the shift ratio; both may be NULL);
+ * *zero_out = 0 (may be NULL: the loss accumulator mdm_loss_fwd_bwd adds to -- this is the first launch of a step).
+ * Philox4x32-10 keyed by rng[0]=seed, rng[1]=offset (device memory). */
 int mdm_draw_timesteps(const uint64_t* rng, const int32_t* used, int n_used, const double* table,
                        const float* wtab, int N, float* t_out, double* amount_out, float* weight_out,
-                       int32_t* idx_out, void* stream);
+                       int32_t* idx_out, const double* table2, double* out2, float* zero_out, void* stream);
 
 /* Thresholding mask + fill + degrade (scheduler.py:286-323 == 438-477 == 572-598).
  *   u: [N][Cm*HW] uniforms (replay mode) or NULL (device Philox, stream id `rng_stream`);
@@ -289,7 +291,8 @@ int mdm_index_mask(const double* count, int count_stride, const uint64_t* rng, i
  *         3 'noise_reduction' (zc=1,zhw=HW,normal), 4 'noise_with_perturbation' (zc=3,zhw=HW,normal),
  *         5 'noise_std_reduction' (zc=3,zhw=HW; s = N(noise_mean, ratio_n); a replayed z IS the shift);
  *   ratio: [N] double; per_column != 0 reproduces the reference's N==W broadcast (ratio indexed by column w);
- *   outputs: s [N][C][HW] (may be NULL), x_in fp32 NCHW (may be NULL), x_in_nhwc (dtype, Cp channels; may be NULL). */
+ *   outputs: s [N][C][HW] (may be NULL), x_in fp32 NCHW (may be NULL), x_in_nhwc (dtype, Cp channels; may be NULL: only the
+ *   C real channels of every pixel are written -- the caller provides the pad channels zeroed once, they never change). */
 int mdm_shift(const float* x_t, const float* z, const double* ratio, const uint64_t* rng, int rng_stream,
               int kind, float noise_mean, int per_column, int N, int C, int H, int W,
               float* s, float* x_in, int dtype, void* x_in_nhwc, int Cp, void* stream);
@@ -334,7 +337,7 @@ int mdm_col_argmax(const float* S, int M, int B, float* val, int64_t* idx, void*
  * Optimizer: global-norm clip + AdamW + EMA + bf16 weight shadow in one pass over
  * flat fp32 buffers (trainer_masked_mean_shift.py:163-172, main_train_masked.py:134-141).
  *   hp (device, 8 floats): lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ema_decay
- *   mdm_sqnorm accumulates sum(g^2) into *out (caller zeroes it).
+ *   mdm_sqnorm stores sum(g^2) to *out (two-stage, fixed summation order: bit-identical on every rank).
  *   clip_coef = min(1, max_norm / (sqrt(*sqnorm) * gscale_inv + 1e-6)); g is multiplied by gmul first
  *   (gmul = 1/world for the DP mean).  ema / shadow may be NULL.
  * ------------------------------------------------------------------------- */

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(float* out, int nblk)
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) *out += (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x == 0) *out = (part[0] + part[1]) + (part[2] + part[3]);      // stored: no zeroing launch in front
 }
 
 // hp: lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, ema_decay

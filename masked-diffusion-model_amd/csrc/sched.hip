@@ -17,7 +17,8 @@ __device__ __forceinline__ uint4 philox_at(const uint64_t* rng, int stream_id, u
 
 __global__ void draw_timesteps_kernel(const uint64_t* rng, const int32_t* used, int n_used, const double* table,
                                       const float* wtab, int N, float* t_out, double* amount_out, float* weight_out,
-                                      int32_t* idx_out) {
+                                      int32_t* idx_out, const double* table2, double* out2, float* zero_out) {
+    if (zero_out && blockIdx.x == 0 && threadIdx.x == 0) *zero_out = 0.f;      // the step's loss accumulator (mdm_loss_fwd_bwd adds)
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     uint4 r = philox_at(rng, 0, (uint64_t)n);
@@ -27,6 +28,7 @@ __global__ void draw_timesteps_kernel(const uint64_t* rng, const int32_t* used, 
     if (amount_out) amount_out[n] = table[t - 1];
     if (weight_out) weight_out[n] = wtab ? wtab[idx] : 1.f;
     if (idx_out) idx_out[n] = idx;
+    if (out2) out2[n] = table2[t - 1];
 }
 
 // One workgroup per image.  Pass A (only for data-dependent fills): masked sums per channel.
@@ -291,10 +293,11 @@ static inline int sgrid(int64_t n) {
 using namespace mdm;
 
 extern "C" int mdm_draw_timesteps(const uint64_t* rng, const int32_t* used, int n_used, const double* table, const float* wtab,
-                                  int N, float* t_out, double* amount_out, float* weight_out, int32_t* idx_out, void* stream) {
-    MDM_REQUIRE(rng && used && table && n_used > 0 && N > 0, "draw_timesteps: bad arguments");
+                                  int N, float* t_out, double* amount_out, float* weight_out, int32_t* idx_out, const double* table2,
+                                  double* out2, float* zero_out, void* stream) {
+    MDM_REQUIRE(rng && used && table && n_used > 0 && N > 0 && (!out2 || table2), "draw_timesteps: bad arguments");
     hipLaunchKernelGGL(draw_timesteps_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rng, used, n_used, table,
-                       wtab, N, t_out, amount_out, weight_out, idx_out);
+                       wtab, N, t_out, amount_out, weight_out, idx_out, table2, out2, zero_out);
     return launch_status("draw_timesteps");
 }
 
@@ -331,15 +334,9 @@ extern "C" int mdm_shift(const float* x_t, const float* z, const double* ratio, 
     const int64_t total = (int64_t)N * C * H * W;
     if (x_in_nhwc) MDM_REQUIRE(Cp >= C && Cp % 8 == 0, "shift: bad Cp");
     if (dtype == MDM_BF16) {
-        if (x_in_nhwc && Cp > C)
-            hipLaunchKernelGGL((zero_pad_channels_kernel<bf16_t>), dim3(cdiv((int64_t)N * H * W * (Cp - C), 256)), dim3(256), 0, st,
-                               (bf16_t*)x_in_nhwc, C, Cp, (int64_t)N * H * W);
         hipLaunchKernelGGL((shift_kernel<bf16_t>), dim3(sgrid(total)), dim3(256), 0, st, x_t, z, ratio, rng, rng_stream, kind,
                            noise_mean, per_column, N, C, H, W, s, x_in, (bf16_t*)x_in_nhwc, Cp);
     } else {
-        if (x_in_nhwc && Cp > C)
-            hipLaunchKernelGGL((zero_pad_channels_kernel<float>), dim3(cdiv((int64_t)N * H * W * (Cp - C), 256)), dim3(256), 0, st,
-                               (float*)x_in_nhwc, C, Cp, (int64_t)N * H * W);
         hipLaunchKernelGGL((shift_kernel<float>), dim3(sgrid(total)), dim3(256), 0, st, x_t, z, ratio, rng, rng_stream, kind,
                            noise_mean, per_column, N, C, H, W, s, x_in, (float*)x_in_nhwc, Cp);
     }

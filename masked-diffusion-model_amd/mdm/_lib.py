@@ -74,7 +74,7 @@ _PROTOS = {
     "mdm_add3": ([i32, vp, vp, vp, i64, vp], i32),
     "mdm_nchw_to_nhwc": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "mdm_nhwc_to_nchw": ([i32, vp, vp, i32, i32, i32, i32, i32, vp], i32),
-    "mdm_draw_timesteps": ([vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp], i32),
+    "mdm_draw_timesteps": ([vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp], i32),
     "mdm_degrade": ([vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp], i32),
     "mdm_index_mask": ([vp, i32, vp, i32, i32, i32, i32, vp, vp], i32),
     "mdm_shift": ([vp, vp, vp, vp, i32, i32, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp], i32),

@@ -60,7 +60,6 @@ class AdamW:
     def emit_update(self, ema_buf=None, max_norm=1.0, gmul=1.0):
         """Enqueue (or record) grad-norm + clip + AdamW + EMA + bf16 shadow over the flat buffers."""
         st = self.store
-        ops.fill(self.sqnorm, 0.0)
         call("mdm_sqnorm", ptr(st.G), st.size, ptr(self.sqnorm), stream())
         call("mdm_adamw_ema", ptr(st.P), ptr(st.G), ptr(self.m), ptr(self.v), ptr(ema_buf), ptr(st.Pb), st.size,
              ptr(self.hp), ptr(self.sqnorm), float(max_norm), float(gmul), stream())

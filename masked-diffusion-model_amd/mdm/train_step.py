@@ -67,7 +67,6 @@ class TrainStep:
              float(getattr(a, "noise_mean", 0.0)), per_col, N, C, H, W, ptr(self.s), ptr(self.x_in), m.dt,
              ptr(m.x_in.data), m.cin_p, stream())
         m.forward_plan.run() if _lib._recording is None else _lib._recording.extend(m.forward_plan)
-        ops.fill(self.loss, 0.0)
         call("mdm_loss_fwd_bwd", m.dt, ptr(m.y_out.data), ptr(self.x_in), ptr(self.s) if kind != 0 else None, ptr(self.x0),
              ptr(self.w) if weights_on else None, N, C, H, W, m.cout_p, 1.0, ptr(m.y_out.grad), ptr(self.loss), stream())
 
@@ -108,6 +107,7 @@ class TrainStep:
             self.ratio.copy_(torch.index_select(S.ratio_dev, 0, (t.int() - 1).to(dev)))
             z = S._shift_draws(N, C, H, W, self.ratio.cpu()).to(dev).contiguous()
         m.t_in.copy_(t.to(torch.float32))
+        self.loss.zero_()                   # (the device path clears it in its first launch, mdm_draw_timesteps)
         self._emit_forward_loss(u, z, mask_in, Cm, weights_on)
         m.store.G.zero_()
         m.run_backward()
@@ -154,9 +154,7 @@ class TrainStep:
         n_used = self.used_dev.numel()
         S.dev_rng.advance()                 # first launch of the step (part of the captured graph): a fresh Philox offset
         call("mdm_draw_timesteps", rng, ptr(self.used_dev), n_used, ptr(self.table_dev), ptr(self.wtab_dev), N,
-             ptr(m.t_in), ptr(self.amount), ptr(self.w), ptr(self.tidx), stream())
-        call("mdm_draw_timesteps", rng, ptr(self.used_dev), n_used, ptr(S.ratio_dev), None, N,
-             None, ptr(self.ratio), None, None, stream())
+             ptr(m.t_in), ptr(self.amount), ptr(self.w), ptr(self.tidx), ptr(S.ratio_dev), ptr(self.ratio), ptr(self.loss), stream())
         mask_in, Cm = None, 1
         if a.select_degrade_pixel == "indexing":
             call("mdm_index_mask", ptr(self.amount), 1, rng, 1, N, C, H * W, ptr(self.mask), stream())
