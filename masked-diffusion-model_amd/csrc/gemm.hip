@@ -2469,7 +2469,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         if (hb) {
             const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
             rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 2>(d, s) : launch_halo<256, 6, 2>(d, s))
-                 : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 2>(d, s) : npw <= 4 ? launch_halo<128, 4, 2>(d, s) : launch_halo<128, 6, 2>(d, s))
+                 // (128-pixel tiles: three filter stages -- 3.951 vs 3.960 ms/step with two; the 256-pixel tiles have room for two)
+                 : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 3>(d, s) : npw <= 4 ? launch_halo<128, 4, 3>(d, s) : launch_halo<128, 6, 3>(d, s))
                  // whole-image 64-pixel tiles (4x4 / 8x8 maps): the loop is the filter stream of ONE workgroup (64 output
                  // channels x 9 C x 2 B) and these maps give only 32-128 such workgroups: 32 output channels per workgroup
                  // halve the stream and double the workgroups.  A fused GroupNorm epilogue needs whole groups inside the
