@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-timed replay (kernel-count profiles: every profiled launch then belongs to a whole step)")
     ap.add_argument("--wgrad-group-mb", type=float, default=None, help=argparse.SUPPRESS)      # experiments only
     ap.add_argument("--overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-pair", action="store_true", help=argparse.SUPPRESS)                  # experiments only: every convolution its own launch
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
@@ -230,6 +231,8 @@ def main():
     xk = {}
     if opt_.wgrad_group_mb is not None:
         xk["wgrad_group_bytes"] = int(opt_.wgrad_group_mb * (1 << 20))
+    if opt_.no_pair:
+        xk["pair_convs"] = False
     model = mdm.UNet(cfg, N=N, H=32, W=32, dtype=dt, seed=0, use_graph=not opt_.no_graph, **xk)   # same weights on every rank
     optim = mdm.AdamW(model, lr=1e-4)
     ema = mdm.EMA(model, decay=args.ema_max_decay, inv_gamma=args.ema_inv_gamma, power=args.ema_power)
@@ -276,8 +279,8 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         with _lib.Recording() as front:
             step._emit_device_front()
-        # the family = every bf16 mdm_gemm call plus the grouped weight-gradient launches (incl. their split-K sums)
-        pick = lambda rec: (lambda i, name: (name == "mdm_gemm" and rec.flops.get(i, (0, -1))[1] == dt) or
+        # the family = every bf16 mdm_gemm / mdm_gemm_pair call plus the grouped weight-gradient launches (incl. their split-K sums)
+        pick = lambda rec: (lambda i, name: (name in ("mdm_gemm", "mdm_gemm_pair") and rec.flops.get(i, (0, -1))[1] == dt) or
                             name == "mdm_wgrad_group_launch")
         tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
         reps = 3

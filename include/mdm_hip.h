@@ -115,6 +115,11 @@ typedef struct mdm_gemm_desc {
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
+/* Two INDEPENDENT contractions (neither reads what the other writes), in one launch where the pair is a 3x3 halo convolution
+ * `a` and a 1x1 convolution `b` of the shapes a ResidualBlock produces (conv1 next to the skip projection, unet6.py:350-362;
+ * conv2's data gradient next to the skip projection's): the workgroups of `b` follow those of `a` in the same grid.
+ * Every other pair runs as mdm_gemm(a) then mdm_gemm(b): the results are the same either way. */
+int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b_host, void* stream);
 /* What mdm_gemm would choose for this descriptor given unlimited workspace: the split count and the
  * workspace bytes it needs (0 when it would not use partial slabs).  No launch. */
 int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out);

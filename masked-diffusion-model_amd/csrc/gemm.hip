@@ -1454,26 +1454,27 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define MDM_T(...)
 #endif
 
+// (device body: the kernel proper below, and one role of conv_pair_kernel.  bx / gx / bz stand for blockIdx.x / gridDim.x /
+// blockIdx.z of a launch of its own)
 template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false>
-__global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_desc d) {
+__device__ __forceinline__ void conv_lin2_body(const mdm_gemm_desc& d, char* ring, const int bx, const int gx, const int bz) {
     constexpr int BK = 64, NW = WR * WC * WK;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW, G = GA + GB;
     constexpr int WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16, KSN = 2 / WK;
     static_assert(GA >= 1 && GB >= 1 && MI >= 1 && NI >= 1 && KSN >= 1, "tile too small for this wave layout");
-    extern __shared__ __attribute__((aligned(1024))) char ring[];
     MDM_T(const unsigned long long t_entry = stamp_now();)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wk = wave / (WR * WC), wrc = wave % (WR * WC), wr = wrc / WC, wc = wrc % WC;
     const int tiles_n = (d.N + BN - 1) / BN;
-    const int tile_i = xcd_remap((int)blockIdx.x, (int)gridDim.x);     // XCD-aware tile order: see conv_halo_kernel
+    const int tile_i = xcd_remap(bx, gx);                              // XCD-aware tile order: see conv_halo_kernel
     const int tile_m = udiv_small(tile_i, tiles_n);                    // (scalar integer divisions cost ~200 cycles each here)
     const int m0 = tile_m * BM, n0 = (tile_i - tile_m * tiles_n) * BN;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int sk = d.splitk < 1 ? 1 : d.splitk;
-    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.nouter = 1; z.ks = blockIdx.z;
+    ZInfo z; z.batch = 0; z.tap = 0; z.kbeg = 0; z.kend = d.K; z.outer = 0; z.nouter = 1; z.ks = bz;
 
     const int r_sub = lane >> 3, r_lch = (lane & 7) ^ r_sub;
     const int sgn = d.transposed ? -1 : 1;
@@ -1734,7 +1735,7 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-        const unsigned widx = (blockIdx.z * gridDim.x + blockIdx.x) * NW + wave;
+        const unsigned widx = (unsigned)(bz * gx + bx) * NW + wave;
         if (widx < 4096) {
             unsigned long long* r = g_stamp_buf + widx * 32;
             r[0] = tw; r[1] = tb; r[2] = ti; r[3] = tc; r[4] = nk; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
@@ -1744,6 +1745,12 @@ __global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_d
 #endif
 }
 
+
+template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false>
+__global__ __launch_bounds__(64 * WR * WC * WK) void conv_lin2_kernel(mdm_gemm_desc d) {
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
+    conv_lin2_body<BM, BN, NSTAGE, WR, WC, WK, PIPE, STAG>(d, ring, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z);
+}
 
 // ----------------------------------------------------------------------------
 // wgrad_lin: weight gradient of a stride-1 "same" convolution (layout 2: k = output pixel, rows of both
@@ -1999,7 +2006,7 @@ template <int NPW, int APT, int D, int TG> constexpr int halo_vmcnt(int g) {    
 // slab are dealt out APT per group over the first groups, so that they are all older than the filter tiles the
 // first group of that slab waits for.
 template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
-__global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
+__device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
     constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
     constexpr int NG = 9 / TG;                                    // groups per channel slab
     constexpr int D = TG == 1 ? (NSB == 4 ? 3 : NSB - 2) : NSB - 1;  // refill distance (groups)
@@ -2007,7 +2014,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     static_assert(9 % TG == 0 && D >= 1 && D < NG && APT * (NG - D) >= NPW, "conv_halo: halo pieces do not fit in front of the refill distance");
     static_assert(MI >= 1 && NI >= 1, "conv_halo: tile too small for 4 x 2 waves");
     constexpr int B_BYTES = BN * 128, STAGE_B = TG * B_BYTES;
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
     MDM_T(const unsigned long long t_entry = stamp_now();)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -2030,7 +2036,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     // pixel tiles the same filter slabs -- handing each XCD a CONTIGUOUS eighth of the tile list lets them meet in ONE L2
     // instead of eight.  No effect on time at cfg2 (the loop is bound by the CU's intake, not by L2 misses); it is there
     // for the L2-side traffic (FETCH_SIZE), which counts every XCD's own fetch of the same line.
-    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int bid = xcd_remap(bx, gx);
     const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
     const int img = m0 >> p_sh, y0 = (m0 >> ow_sh) & (OH - 1);
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
@@ -2167,7 +2173,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-        const unsigned widx = blockIdx.x * NW + wave;
+        const unsigned widx = (unsigned)bx * NW + wave;
         if (widx < 4096) {
             unsigned long long* r = g_stamp_buf + widx * 32;
             r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = NCS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
@@ -2175,6 +2181,25 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
         }
     }
 #endif
+}
+
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
+__global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    conv_halo_body<BM, NPW, BN, NSB, TG>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// TWO independent convolutions in one launch (mdm_gemm_pair): workgroups [0, na) run the 3x3 halo convolution `a`, the rest
+// the 1x1 convolution `b` (conv_lin2).  The pairs are the ResidualBlock's conv1 next to its skip projection in the forward
+// (both only need the block input / its norm) and conv2's data gradient next to the skip projection's in the backward (both
+// read the block's dY): the 1x1 launch -- 7-15 us, mostly launch, prologue and drain -- disappears into the tail of its
+// neighbour, whose workgroups are dispatched first.  Both bodies are 512-thread workgroups on dynamic LDS.
+template <int BM, int NPW, int BN, int NSB, int LBM, int LBN, int LNS, int LWR, int LWC>
+__global__ __launch_bounds__(512) void conv_pair_kernel(mdm_gemm_desc a, mdm_gemm_desc b, int na) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    static_assert(LWR * LWC == 8, "conv_pair: both roles are 8-wave workgroups");
+    if ((int)blockIdx.x < na) conv_halo_body<BM, NPW, BN, NSB, 3>(a, lds, (int)blockIdx.x, na);
+    else conv_lin2_body<LBM, LBN, LNS, LWR, LWC, 1, true, false>(b, lds, (int)blockIdx.x - na, (int)gridDim.x - na, 0);
 }
 
 // ----------------------------------------------------------------------------
@@ -2429,17 +2454,50 @@ static int resolve(const mdm_gemm_desc* dh, bool planning, Resolved& r) {
     return 0;
 }
 
-static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
-    Resolved r;
-    if (int rc = resolve(dh, false, r)) return rc;
-    const mdm_gemm_desc& d = r.d;
-    const bool big = r.big;
+// Which kernel of the conv_halo / conv_lin2 family a bf16 forward / data-gradient convolution takes (0: none of them).
+// Tile choice (measured per shape): the largest tile that still gives the chip ~one workgroup per CU -- whole-row halo tiles
+// of 256 / 128 pixels on the 32x32 / 16x16 maps; 64-pixel whole-image tiles on 4x4 / 8x8 (the loop there is the filter stream
+// of ONE workgroup and these maps give only 32-128 of them, so 32 output channels per workgroup: half the stream, twice the
+// workgroups; a fused GroupNorm epilogue needs whole groups inside the tile, i.e. groups of <= 32 channels); for everything
+// else conv_lin2 at 128x128 / 64x128 (the 16x16 maps: +20 % over 64x64) / 64x64.
+// (128-pixel halo tiles run three filter stages -- 3.951 vs 3.960 ms/step with two; the 256-pixel tiles have room for two.)
+enum ConvVar { CV_NONE = 0, CV_H256_4, CV_H256_6, CV_H128_3, CV_H128_4, CV_H128_6, CV_H64_2_32, CV_H64_3_32, CV_H64_2_64, CV_H64_3_64,
+               CV_L128, CV_L64x128, CV_L64 };
+static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned grid_z) {
+    if (!(d.dtype == MDM_BF16 && ring_eligible(d) && d.layout == 0 && d.conv &&
+          (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0)) && d.C0 <= 4096 && d.C1 <= 4096 &&
+          (d.ups == 0 || (d.splitk <= 1 && halo_tile(d) != 0)) && d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0))
+        return CV_NONE;
+    const int64_t t_mid = (int64_t)cdiv(d.M, 64) * cdiv(d.N, 128) * grid_z;
+    const int hb = d.splitk <= 1 ? halo_tile(d) : 0;
+    if (hb) {
+        const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
+        if (hb == 256) return npw <= 4 ? CV_H256_4 : CV_H256_6;
+        if (hb == 128) return npw <= 3 ? CV_H128_3 : npw <= 4 ? CV_H128_4 : CV_H128_6;
+        if (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32)) return npw <= 2 ? CV_H64_2_32 : CV_H64_3_32;
+        return npw <= 2 ? CV_H64_2_64 : CV_H64_3_64;
+    }
+    if (r.big) return CV_L128;
+    if (d.N >= 128 && t_mid >= kBigMinTiles) return CV_L64x128;
+    return CV_L64;
+}
+
+static int check_fused_gn(const mdm_gemm_desc& d) {
     if (d.gnb_x)
         MDM_REQUIRE(mdm_gemm_can_fuse_gn_bwd(&d, d.gnb_G) == 1 && d.gnb_stats && d.gnb_gamma && d.gnb_beta && d.gnb_dgamma && d.gnb_dbeta,
                     "gemm: gnb_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_bwd)");
     if (d.gnf_out)
         MDM_REQUIRE(mdm_gemm_can_fuse_gn_fwd(&d, d.gnf_G) == 1 && d.gnf_gamma && d.gnf_beta && d.gnf_stats,
                     "gemm: gnf_* epilogue on a descriptor that does not qualify (mdm_gemm_can_fuse_gn_fwd)");
+    return 0;
+}
+
+static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
+    Resolved r;
+    if (int rc = resolve(dh, false, r)) return rc;
+    const mdm_gemm_desc& d = r.d;
+    const bool big = r.big;
+    if (int rc0 = check_fused_gn(d)) return rc0;
     MDM_REQUIRE(r.tiles < (1ll << 31), "gemm: grid too large");
     dim3 grid((unsigned)r.tiles, 1, (unsigned)(r.zouter * d.splitk));
     MDM_REQUIRE(grid.z <= 65535, "gemm: grid.z=%u too large", grid.z);
@@ -2459,32 +2517,21 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         const bool big32 = d.M >= 128 && d.N >= 128 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * grid.z >= kBigMinTiles;
         rc = big32 ? launch_f32_mfma<128, 128>(d, dim3((unsigned)((int64_t)cdiv(d.M, 128) * cdiv(d.N, 128)), 1, grid.z), s)
                    : launch_f32_mfma<64, 64>(d, grid, s);
-    } else if (ring_eligible(d) && d.layout == 0 && d.conv &&
-               (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0)) && d.C0 <= 4096 && d.C1 <= 4096 &&
-               (d.ups == 0 || (d.splitk <= 1 && halo_tile(d) != 0)) && d.KH * d.KW <= 9 && (d.KH * d.KW) % d.splitk == 0) {
-        // tile choice (measured per shape): the largest tile that still gives the chip ~one workgroup per CU --
-        // 128x128 for the 32x32 maps, 64x128 for the 16x16 maps (+20 % over 64x64), 64x64 below that
-        const int64_t t_mid = (int64_t)cdiv(d.M, 64) * cdiv(d.N, 128) * grid.z;
-        const int hb = d.splitk <= 1 ? halo_tile(d) : 0;
-        if (hb) {
-            const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
-            rc = hb == 256 ? (npw <= 4 ? launch_halo<256, 4, 2>(d, s) : launch_halo<256, 6, 2>(d, s))
-                 // (128-pixel tiles: three filter stages -- 3.951 vs 3.960 ms/step with two; the 256-pixel tiles have room for two)
-                 : hb == 128 ? (npw <= 3 ? launch_halo<128, 3, 3>(d, s) : npw <= 4 ? launch_halo<128, 4, 3>(d, s) : launch_halo<128, 6, 3>(d, s))
-                 // whole-image 64-pixel tiles (4x4 / 8x8 maps): the loop is the filter stream of ONE workgroup (64 output
-                 // channels x 9 C x 2 B) and these maps give only 32-128 such workgroups: 32 output channels per workgroup
-                 // halve the stream and double the workgroups.  A fused GroupNorm epilogue needs whole groups inside the
-                 // tile: groups of <= 32 channels
-                 : (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32))
-                     ? (npw <= 2 ? launch_halo<64, 2, 3, 32>(d, s) : launch_halo<64, 3, 3, 32>(d, s))
-                     : (npw <= 2 ? launch_halo<64, 2, 3>(d, s) : launch_halo<64, 3, 3>(d, s));
-        } else if (big) {
-            rc = launch_lin2<128, 128, 3, 4, 2>(d, grid, s);
-        } else if (d.N >= 128 && t_mid >= kBigMinTiles) {
-            dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
-            rc = launch_lin2<64, 128, 3, 2, 4>(d, g2, s);
-        } else {
-            rc = launch_lin2<64, 64, 4, 4, 2>(d, grid, s);
+    } else if (const ConvVar cv = conv_variant(d, r, grid.z)) {
+        const dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
+        switch (cv) {
+            case CV_H256_4: rc = launch_halo<256, 4, 2>(d, s); break;
+            case CV_H256_6: rc = launch_halo<256, 6, 2>(d, s); break;
+            case CV_H128_3: rc = launch_halo<128, 3, 3>(d, s); break;
+            case CV_H128_4: rc = launch_halo<128, 4, 3>(d, s); break;
+            case CV_H128_6: rc = launch_halo<128, 6, 3>(d, s); break;
+            case CV_H64_2_32: rc = launch_halo<64, 2, 3, 32>(d, s); break;
+            case CV_H64_3_32: rc = launch_halo<64, 3, 3, 32>(d, s); break;
+            case CV_H64_2_64: rc = launch_halo<64, 2, 3>(d, s); break;
+            case CV_H64_3_64: rc = launch_halo<64, 3, 3>(d, s); break;
+            case CV_L128: rc = launch_lin2<128, 128, 3, 4, 2>(d, grid, s); break;
+            case CV_L64x128: rc = launch_lin2<64, 128, 3, 2, 4>(d, g2, s); break;
+            default: rc = launch_lin2<64, 64, 4, 4, 2>(d, grid, s); break;
         }
     } else if (wgrad_lin_eligible(d)) {
         MDM_REQUIRE((int64_t)grid.x * grid.z < (1ll << 30), "gemm: grid too large");
@@ -2526,6 +2573,57 @@ using namespace mdm;
 
 extern "C" int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream) {
     return gemm_launch(desc_host, pick_stream(stream));
+}
+
+// ---- two independent convolutions in one launch (conv_pair_kernel)
+template <int BM, int NPW, int BN, int NSB, int LBM, int LBN, int LNS, int LWR, int LWC>
+static int launch_pair(const mdm_gemm_desc& a, const mdm_gemm_desc& b, int nb, hipStream_t s) {
+    const int NPA = halo_pieces(BM, a.OH, a.OW);
+    int bytes = 2 * NPA * 1024 + NSB * 3 * BN * 128 + 1024;                    // as launch_halo
+    if (bytes < BM * BN * 4) bytes = BM * BN * 4;
+    if (BM == 64 && a.gnb_x && bytes < 16384 + 65536 + 4096 + 512) bytes = 16384 + 65536 + 4096 + 512;
+    constexpr int lin_bytes = LNS * (LBM + LBN) * 64 * 2;                      // as launch_lin2
+    if (bytes < lin_bytes) bytes = lin_bytes;
+    MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_pair: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
+    static int configured = 0;
+    if (configured < bytes) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<BM, NPW, BN, NSB, LBM, LBN, LNS, LWR, LWC>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = bytes;
+    }
+    const int na = (int)((int64_t)(a.M / BM) * (a.N / BN));
+    hipLaunchKernelGGL((conv_pair_kernel<BM, NPW, BN, NSB, LBM, LBN, LNS, LWR, LWC>), dim3((unsigned)(na + nb)), dim3(512), bytes, s, a, b, na);
+    return 0;
+}
+
+extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b_host, void* stream) {
+    hipStream_t s = pick_stream(stream);
+    Resolved ra, rb;
+    if (int rc = resolve(a_host, false, ra)) return rc;
+    if (int rc = resolve(b_host, false, rb)) return rc;
+    const mdm_gemm_desc &a = ra.d, &b = rb.d;
+    if (int rc = check_fused_gn(a)) return rc;
+    if (int rc = check_fused_gn(b)) return rc;
+    const unsigned za = (unsigned)(ra.zouter * a.splitk), zb = (unsigned)(rb.zouter * b.splitk);
+    const ConvVar va = conv_variant(a, ra, za), vb = conv_variant(b, rb, zb);
+    // `b` must be a conv_lin2 launch of its own with no second stage (no split reduction), `a` a halo launch; the four pairs
+    // below are the ones a unet6 step produces (4x4, 8x8, 16x16, 32x32 maps).  Anything else: two launches, same results.
+    const bool b_plain = zb == 1 && !rb.tap_split && !(b.splitk > 1) && rb.tiles < (1ll << 20) && !b.gnb_x && !b.gnf_out;
+    int rc = -2;
+    if (b_plain && za == 1) {
+        const int nb64 = (int)rb.tiles, nb64x128 = (int)((int64_t)cdiv(b.M, 64) * cdiv(b.N, 128));
+        if (va == CV_H64_2_32 && vb == CV_L64) rc = launch_pair<64, 2, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
+        else if (va == CV_H64_3_32 && vb == CV_L64) rc = launch_pair<64, 3, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
+        else if (va == CV_H128_3 && vb == CV_L64x128) rc = launch_pair<128, 3, 64, 3, 64, 128, 3, 2, 4>(a, b, nb64x128, s);
+        else if (va == CV_H256_6 && vb == CV_L128) rc = launch_pair<256, 6, 64, 2, 128, 128, 3, 4, 2>(a, b, nb64, s);
+    }
+    if (rc == -2) {
+        rc = gemm_launch(a_host, s);
+        if (rc == 0) rc = gemm_launch(b_host, s);
+        return rc;
+    }
+    if (rc) return rc;
+    return launch_status("gemm pair launch");
 }
 extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
     if (!desc_host || G <= 0) return 0;

@@ -42,6 +42,7 @@ _PROTOS = {
     "mdm_version": ([], i32),
     "mdm_device_count": ([], i32),
     "mdm_gemm": ([C.POINTER(GemmDesc), vp], i32),
+    "mdm_gemm_pair": ([C.POINTER(GemmDesc), C.POINTER(GemmDesc), vp], i32),
     "mdm_wgrad_group_accepts": ([C.POINTER(GemmDesc)], i32),
     "mdm_wgrad_group_create": ([C.POINTER(GemmDesc), i32, vp, i64, C.POINTER(i64), C.POINTER(vp)], i32),
     "mdm_wgrad_group_launch": ([vp, vp], i32),
@@ -346,6 +347,18 @@ class WgradGroup:
 def wgrad_group_accepts(**kw):
     kw.pop("_flops", None)
     return bool(load().mdm_wgrad_group_accepts(C.byref(_desc(kw))))
+
+
+def gemm_pair(kw_a, kw_b):
+    """Two independent contractions as ONE call (mdm_gemm_pair): -> (desc_a, desc_b)."""
+    fa, fb = kw_a.pop("_flops", None), kw_b.pop("_flops", None)
+    da, db = _desc(kw_a), _desc(kw_b)
+    if _recording is not None:
+        _recording.keep.append((da, kw_a, db, kw_b))
+        fl = lambda f, d: f if f is not None else 2.0 * d.M * d.N * d.K * d.batch
+        _recording.flops[len(_recording.calls)] = (fl(fa, da) + fl(fb, db), da.dtype)
+    call("mdm_gemm_pair", C.byref(da), C.byref(db), stream())
+    return da, db
 
 
 def gemm(**kw):

@@ -65,8 +65,17 @@ def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, re
     """out[N,OH,OW,Cout] = conv(concat(src0,src1), w[tap][Cout][Cin]) + bias + rowvec[n] + resid.
     Returns the descriptor.  `gnf` = dict(out, gamma, beta, stats, G, silu, eps): also the GroupNorm of the result in the
     same launch (only where conv_fwd_can_fuse_gn says so); `fuse_gn_fwd(desc, ...)` sets it on a RECORDED call afterwards."""
+    return _lib.gemm(**conv_fwd_fields(dt, g, src0, src1, w, bias, out, rowvec, rv_ld, resid, out_f32, ws, gnf))
+
+
+def conv_fwd_pair(fields_a, fields_b):
+    """Two independent forward convolutions (conv_fwd_fields each) as one call: -> (desc_a, desc_b)."""
+    return _lib.gemm_pair(fields_a, fields_b)
+
+
+def conv_fwd_fields(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None, gnf=None):
     extra = {} if gnf is None else _gnf_fields(gnf)
-    return _lib.gemm(**extra, dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
+    return dict(**extra, dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
               conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
               pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,
               src0=src0, src1=src1, ld0=g.C0, ld1=g.C1, B=w, ldb=g.Cin, wtap=g.Cout * g.Cin,
@@ -110,6 +119,10 @@ def _dgrad_t_fields(dt, g, dy, wT, dst0, acc0, dst1, acc1, ws):
 
 
 def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None, gnb=None):
+    _lib.gemm(**conv_dgrad_t_fields(dt, g, dy, wT, dst0, acc0, dst1, acc1, ws, gnb))
+
+
+def conv_dgrad_t_fields(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None, gnb=None):
     """Same gradient as conv_dgrad but with per-tap TRANSPOSED filters wT[tap][Cin][Cout]: both operands
     are k-contiguous (layout 0), the path the forward uses.  `gnb` (see conv_dgrad_t_can_fuse_gn_bwd): the conv's input
     was z = silu?(GroupNorm(x)); dict(x, stats, gamma, beta, dgamma, dbeta, G, silu[, sum_img, sum_ld, sum_all]) makes
@@ -120,7 +133,7 @@ def conv_dgrad_t(dt, g: ConvGeom, dy, wT, dst0, acc0, dst1=None, acc1=0, ws=None
                  gnb_dgamma=gnb["dgamma"], gnb_dbeta=gnb["dbeta"], gnb_G=int(gnb.get("G", 32)), gnb_silu=int(bool(gnb["silu"])),
                  gnb_sum_img=gnb.get("sum_img"), gnb_sum_ld=int(gnb.get("sum_ld", 0)), gnb_sum_all=gnb.get("sum_all"),
                  gnb_add=gnb.get("add"))
-    _lib.gemm(**f)
+    return f
 
 
 def conv_dgrad_t_can_fuse_gn_bwd(dt, g: ConvGeom, G=32):

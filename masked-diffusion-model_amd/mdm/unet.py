@@ -201,17 +201,32 @@ class _Conv:
         st.declare(self.name + ".weight", "conv" if len(rs) == 4 else "convlin", rs, (g.taps, g.Cout, g.Cin))
         st.declare(self.name + ".bias", "vecpad", (rs[0],), (g.Cout,))
 
-    def fwd(self):
+    def _fwd_fields(self):
         n, st, g = self.net, self.net.store, self.g
         rv, ld = (None, 0)
         if self.fc_slot is not None:
             rv, ld = n.T_all[:, self.fc_slot:], n.fc_total
-        self.fwd_desc = ops.conv_fwd(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
-                                     st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
-                                     resid=self.resid.data if self.resid else None, ws=n.splitk_ws)
+        return ops.conv_fwd_fields(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
+                                   st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
+                                   resid=self.resid.data if self.resid else None, ws=n.splitk_ws)
 
-    def bwd(self):
+    def fwd(self):
+        n = self.net
+        # A ResidualBlock's skip projection (1x1) only needs the block input, like conv1 only needs norm1's output: the two
+        # run as ONE launch (mdm_gemm_pair) when conv1 is reached; conv2 consumes the projection afterwards.
+        if n.pair_convs and getattr(self, "pair_host", None) is not None:
+            return                                      # a skip projection: launched together with its block's conv1
+        mate = getattr(self, "pair_skip", None) if n.pair_convs else None
+        if mate is not None:
+            self.fwd_desc, mate.fwd_desc = ops.conv_fwd_pair(self._fwd_fields(), mate._fwd_fields())
+        else:
+            self.fwd_desc = _lib.gemm(**self._fwd_fields())
+
+    def bwd(self, pair_a=None):
+        """pair_a: descriptor fields of another conv's data gradient (the block's conv2) to launch TOGETHER with this one's."""
         n, st, g = self.net, self.net.store, self.g
+        if getattr(self, "bwd_done", False):            # a skip projection whose backward ran next to conv2's
+            return
         dy = n.grad_for_read(self.out)
         r = self.resid
         per, ld = (None, 0)
@@ -246,6 +261,7 @@ class _Conv:
             else:
                 r.grad, r.grad_written = dy, True      # alias: dy is dead after this op, later ops += into it
         if not s0.needs_grad:
+            assert pair_a is None
             return
         # bf16: the filters come from the per-tap transposed shadow so both operands are k-contiguous
         if n.dt == BF16:
@@ -253,6 +269,18 @@ class _Conv:
             dgrad = lambda *a: ops.conv_dgrad_t(*a, ws=n.splitk_ws)     # small maps split the taps over the grid
         else:
             dgrad, wmat = ops.conv_dgrad, st.w(self.name + ".weight")
+        # conv2 of a ResidualBlock with a skip projection: the projection's whole backward runs HERE, its data gradient in
+        # the same launch as this one's (both read this block's dY; they write different tensors)
+        mate = getattr(self, "pair_skip_bwd", None) if (n.pair_convs and n.dt == BF16 and not g.ups) else None
+
+        def emit(fields):
+            if pair_a is not None:
+                _lib.gemm_pair(pair_a, fields)
+            elif mate is not None:
+                mate.bwd(pair_a=fields)
+                mate.bwd_done = True
+            else:
+                _lib.gemm(**fields)
         nm = getattr(s0, "norm_spec", None)          # the GroupNorm that produced this conv's input (if any)
         if (n.dt == BF16 and nm is not None and nm.src1 is None and s1 is None and not g.ups
                 and ops.conv_dgrad_t_can_fuse_gn_bwd(n.dt, g)):
@@ -265,16 +293,20 @@ class _Conv:
             if prod is not None and ax == 0 and addx is None:
                 sums = dict(sum_img=n.dT_all[:, prod.fc_slot:], sum_ld=n.fc_total, sum_all=st.g(prod.name + ".bias"))
                 prod.sums_by_norm = True
-            ops.conv_dgrad_t(n.dt, g, dy, wmat, gx, ax, ws=n.splitk_ws,
-                             gnb=dict(x=x.data, stats=nm.stats, gamma=st.f(nm.name + ".weight"), beta=st.f(nm.name + ".bias"),
-                                      dgamma=st.g(nm.name + ".weight"), dbeta=st.g(nm.name + ".bias"), G=32, silu=nm.silu,
-                                      add=addx, **sums))
+            emit(ops.conv_dgrad_t_fields(n.dt, g, dy, wmat, gx, ax, ws=n.splitk_ws,
+                                         gnb=dict(x=x.data, stats=nm.stats, gamma=st.f(nm.name + ".weight"), beta=st.f(nm.name + ".bias"),
+                                                  dgamma=st.g(nm.name + ".weight"), dbeta=st.g(nm.name + ".bias"), G=32, silu=nm.silu,
+                                                  add=addx, **sums)))
             nm.bwd_fused = True
         elif g.ups:
             tmp = n.scratch(g.N * g.VH * g.VW * g.Cin)
             dgrad(n.dt, g, dy, wmat, tmp, 0)
             g0, a0, _ = n.grad_for_write(s0)
             ops.sumpool2(n.dt, tmp, g0, a0, g.N, g.IH, g.IW, g.Cin)
+        elif n.dt == BF16:
+            g0, a0, _ = n.grad_for_write(s0)
+            g1, a1, _ = n.grad_for_write(s1) if s1 is not None else (None, 0, None)
+            emit(ops.conv_dgrad_t_fields(n.dt, g, dy, wmat, g0, a0, g1, a1, ws=n.splitk_ws))
         else:
             g0, a0, _ = n.grad_for_write(s0)
             g1, a1, _ = n.grad_for_write(s1) if s1 is not None else (None, 0, None)
@@ -448,7 +480,7 @@ class UNet:
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
     def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True,
-                 group_wgrads=True, wgrad_group_bytes=32 << 20, _dry=False):
+                 group_wgrads=True, wgrad_group_bytes=32 << 20, pair_convs=True, _dry=False):
         if _dry:       # shape/parameter bookkeeping only (no device, no kernels): see `param_table`
             self.cfg, self.N, self.H, self.W, self.dt = dict(cfg), N, H, W, dtype
             self.store = ParamStore()
@@ -470,6 +502,7 @@ class UNet:
         self._scratch_n = 0
         self.use_graph = use_graph
         self.group_wgrads = group_wgrads            # weight gradients of the bf16 path run as grouped launches
+        self.pair_convs = dtype == BF16 and pair_convs   # skip projections share a launch with conv1 / conv2's data gradient
         self.wgrad_group_bytes = wgrad_group_bytes  # a group is flushed once it covers this many bytes of fp32 gradient
         self.pending_wgrads = []
         self.wgrad_groups = []
@@ -555,12 +588,16 @@ class UNet:
             self.fc_slots[pre + ".fc"] = (slot, Cout)
             self.fc_total += Cout
             skip = conv(pre + ".skip", x0, x1, Cout, k=1) if Cin != Cout else x0
+            skip_spec = self.specs[-1] if Cin != Cout else None
             a = norm(pre + ".norm1", x0, x1, True)
             h = conv(pre + ".conv1", a, None, Cout, fc=slot)
             conv1_spec = self.specs[-1]
             b = norm(pre + ".norm2", h, None, True)
             self.specs[-1].producer = conv1_spec          # norm2's backward also emits conv1's bias / time-embedding sums
-            return conv(pre + ".conv2", b, None, Cout, resid=skip)
+            out = conv(pre + ".conv2", b, None, Cout, resid=skip)
+            if skip_spec is not None:                     # launch pairs (see _Conv.fwd / _Conv.bwd)
+                skip_spec.pair_host, conv1_spec.pair_skip, self.specs[-1].pair_skip_bwd = conv1_spec, skip_spec, skip_spec
+            return out
 
         def att(pre, x):                                  # AttentionBlock (unet6.py:296-333)
             C = x.C

@@ -23,6 +23,8 @@ st = torch.cuda.current_stream().cuda_stream
 
 
 def describe(name, args):
+    if name == "mdm_gemm_pair":
+        return describe("mdm_gemm", args[:1]) + "  ||  " + describe("mdm_gemm", args[1:2])
     if name != "mdm_gemm":
         return ""
     d = args[0]._obj            # the call holds C.byref(desc)

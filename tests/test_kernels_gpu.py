@@ -250,6 +250,43 @@ def test_skinny_fp32_linear(M, N, K):
     assert _relerr(D, want) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(32, 4, 512, 256), (32, 8, 512, 256), (32, 16, 384, 256), (32, 32, 256, 128), (2, 8, 64, 64)])
+def test_conv_pair_equals_two_launches(case):
+    """mdm_gemm_pair: a 3x3 convolution and an independent 1x1 convolution (a ResidualBlock's conv1 and skip projection) in ONE
+    launch give bit-identical results to the two launches (the last case is a pair the fused kernel does not cover: fallback)."""
+    from mdm import _lib, ops
+    N, H, Cin, Cout = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(H * 7 + Cin)
+    bf = torch.bfloat16
+    a_in = torch.randn(N, H, H, Cin, generator=g).to(dev, bf)
+    x0 = torch.randn(N, H, H, Cin // 2, generator=g).to(dev, bf)
+    x1 = torch.randn(N, H, H, Cin - Cin // 2, generator=g).to(dev, bf)
+    w3 = (torch.randn(9, Cout, Cin, generator=g) * 0.02).to(dev, bf)
+    w1 = (torch.randn(1, Cout, Cin, generator=g) * 0.05).to(dev, bf)
+    b3, b1 = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    rv = torch.randn(N, Cout, generator=g).to(dev)
+    g3 = ops.ConvGeom(N=N, IH=H, IW=H, C0=Cin, C1=0, Cout=Cout)
+    g1 = ops.ConvGeom(N=N, IH=H, IW=H, C0=Cin // 2, C1=Cin - Cin // 2, Cout=Cout, KH=1, KW=1, pad_t=0, pad_l=0, pad_b=0, pad_r=0)
+    ws = torch.empty(1 << 22, device=dev)
+    outs = []
+    for paired in (False, True):
+        y3 = torch.full((N, H, H, Cout), float("nan"), device=dev, dtype=bf)
+        y1 = torch.full((N, H, H, Cout), float("nan"), device=dev, dtype=bf)
+        fa = ops.conv_fwd_fields(1, g3, a_in, None, w3, b3, y3, rowvec=rv, rv_ld=Cout, ws=ws)
+        fb = ops.conv_fwd_fields(1, g1, x0, x1, w1, b1, y1, ws=ws)
+        if paired:
+            ops.conv_fwd_pair(fa, fb)
+        else:
+            _lib.gemm(**fa); _lib.gemm(**fb)
+        torch.cuda.synchronize()
+        outs.append((y3.float().cpu(), y1.float().cpu()))
+    assert bool(torch.isfinite(outs[1][0]).all()) and bool(torch.isfinite(outs[1][1]).all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want1 = torch.einsum("nhwc,oc->nhwo", torch.cat([x0, x1], -1).float().cpu(), w1[0].float().cpu()) + b1.cpu()
+    assert _relerr(outs[1][1], want1) < _tol("bf16")
+
+
 @pytest.mark.parametrize("M", [4, 32, 100])
 @pytest.mark.parametrize("variant", [None, (True, 0.0)])
 def test_time_embedding_path_kernels(M, variant):
