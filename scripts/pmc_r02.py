@@ -12,7 +12,7 @@ def rows(kind):
 
 
 def family(k):
-    if any(x in k for x in ("conv_halo", "conv_lin2", "wgrad_group", "wgrad_lin", "gemm_ring", "gemm_bf16", "splitk_")):
+    if any(x in k for x in ("conv_halo", "conv_lin2", "conv_pair", "wgrad_group", "wgrad_lin", "gemm_ring", "gemm_bf16", "splitk_")):
         return "contraction"
     if "attn_" in k: return "attention"
     if "gn_" in k: return "groupnorm"
@@ -58,7 +58,7 @@ for fam in sorted(set(f) | set(w) | set(q)):
         d["l2_hit_rate"] = t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
     res["families"][fam] = d
 con = res["families"]["contraction"]
-res["kernel_family"] = "conv_halo / conv_lin2 / wgrad_group / gemm_ring / gemm_bf16 + splitk_* (all bf16 mdm_gemm and mdm_wgrad_group_launch calls)"
+res["kernel_family"] = "conv_halo / conv_lin2 / conv_pair / wgrad_group / gemm_ring / gemm_bf16 + splitk_* (all bf16 mdm_gemm, mdm_gemm_pair and mdm_wgrad_group_launch calls)"
 res["launches_per_step"] = calls
 res["hbm_bytes_per_launch"] = con["hbm_bytes_per_step"] / calls
 res["mfma_busy"] = con.get("mfma_busy")

@@ -4,9 +4,10 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 # divisor = optimizer steps profiled = calls of adamw_kernel (one per step, warm-up and event-timed replays included)
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else float(next(int(r["Calls"]) for r in rows if "adamw_kernel" in r["Name"]))
-cats = collections.OrderedDict((k, [0, 0.0]) for k in ("wgrad_lin", "conv_halo", "wgrad ring<.,.,2", "conv_lin", "gemm_ring other", "gemm_bf16", "gemm_f32", "splitk_reduce", "splitk_epilogue", "gn_bwd", "gn_fwd", "softmax", "adamw/sqnorm/transpose", "other"))
+cats = collections.OrderedDict((k, [0, 0.0]) for k in ("wgrad_lin", "conv_pair", "conv_halo", "wgrad ring<.,.,2", "conv_lin", "gemm_ring other", "gemm_bf16", "gemm_f32", "splitk_reduce", "splitk_epilogue", "gn_bwd", "gn_fwd", "softmax", "adamw/sqnorm/transpose", "other"))
 def cat(n):
     if "gemm_ring_kernel" in n: return "wgrad ring<.,.,2" if ", 2, " in n.split("(")[0] else "gemm_ring other"
+    if "conv_pair" in n: return "conv_pair"
     if "conv_lin" in n: return "conv_lin"
     if "wgrad_lin" in n or "wgrad_group" in n: return "wgrad_lin"
     if "conv_halo" in n: return "conv_halo"
