@@ -1719,6 +1719,13 @@ __device__ __forceinline__ void conv_lin2_body(const mdm_gemm_desc& d, char* rin
     const bool tile_epi = WK == 1 && !(d.splitk > 1 && d.ws) && !d.out_f32 && (d.N & 7) == 0 && (d.N0 & 7) == 0;
     if (tile_epi) {
         __syncthreads();                // every wave is done with the ring (tail DMA landed: vmcnt(0) above)
+        if constexpr (BM == 64 && BN == 64 && WR == 4 && WC == 2 && WK == 1) {
+            // 1x1 convolutions on 4x4 / 8x8 maps (the attention block's projections): a 64-row tile is whole images, like the
+            // 64-pixel halo tiles -- the same fused GroupNorm epilogues apply (lin2_gn_tile)
+            if (d.gnb_x) epilogue_tile_gnb<MI, NI, 64>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+            else if (d.gnf_out) epilogue_tile_gnf<MI, NI, 64>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+            else epilogue_tile<BM, BN, NW, MI, NI>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        } else
         epilogue_tile<BM, BN, NW, MI, NI>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
 #pragma unroll
@@ -2275,12 +2282,13 @@ static int launch_ring(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
 
 template <int BM, int BN, int NSTAGE, int WR, int WC>
 static int launch_lin2(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {         // the software-pipelined variant
-    constexpr int bytes = NSTAGE * (BM + BN) * 64 * 2;
-    static bool configured = false;
-    if (!configured) {
+    int bytes = NSTAGE * (BM + BN) * 64 * 2;
+    if (d.gnb_x && bytes < 16384 + 65536 + 4096 + 512) bytes = 16384 + 65536 + 4096 + 512;      // fused GroupNorm backward (64 x 64 tiles)
+    static int configured = 0;
+    if (configured < bytes) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, 1, true, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        configured = true;
+        configured = bytes;
     }
     hipLaunchKernelGGL((conv_lin2_kernel<BM, BN, NSTAGE, WR, WC, 1, true, false>), grid, dim3(64 * WR * WC), bytes, s, d);
     return 0;
@@ -2461,6 +2469,13 @@ static int resolve(const mdm_gemm_desc* dh, bool planning, Resolved& r) {
 // workgroups; a fused GroupNorm epilogue needs whole groups inside the tile, i.e. groups of <= 32 channels); for everything
 // else conv_lin2 at 128x128 / 64x128 (the 16x16 maps: +20 % over 64x64) / 64x64.
 // (128-pixel halo tiles run three filter stages -- 3.951 vs 3.960 ms/step with two; the 256-pixel tiles have room for two.)
+// 1x1 stride-1 convolution on a 4x4 / 8x8 map whose 64 x 64 conv_lin2 tiles hold whole images and whole channel groups: may
+// carry the fused GroupNorm epilogues of the 64-pixel halo tiles
+static bool lin2_gn_tile(const mdm_gemm_desc& d) {
+    return d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.ups == 0 &&
+           d.IH == d.OH && d.IW == d.OW && d.OH == d.OW && (d.OW == 4 || d.OW == 8) && d.M % 64 == 0 && d.N % 64 == 0 &&
+           d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N0 % 8 == 0 && !d.out_f32 && d.splitk <= 1;
+}
 enum ConvVar { CV_NONE = 0, CV_H256_4, CV_H256_6, CV_H128_3, CV_H128_4, CV_H128_6, CV_H64_2_32, CV_H64_3_32, CV_H64_2_64, CV_H64_3_64,
                CV_L128, CV_L64x128, CV_L64 };
 static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned grid_z) {
@@ -2477,6 +2492,7 @@ static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned 
         if (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32)) return npw <= 2 ? CV_H64_2_32 : CV_H64_3_32;
         return npw <= 2 ? CV_H64_2_64 : CV_H64_3_64;
     }
+    if ((d.gnb_x || d.gnf_out) && lin2_gn_tile(d)) return CV_L64;      // the fused epilogues live on the 64 x 64 tile
     if (r.big) return CV_L128;
     if (d.N >= 128 && t_mid >= kBigMinTiles) return CV_L64x128;
     return CV_L64;
@@ -2615,6 +2631,7 @@ extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b
         if (va == CV_H64_2_32 && vb == CV_L64) rc = launch_pair<64, 2, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H64_3_32 && vb == CV_L64) rc = launch_pair<64, 3, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H128_3 && vb == CV_L64x128) rc = launch_pair<128, 3, 64, 3, 64, 128, 3, 2, 4>(a, b, nb64x128, s);
+        else if (va == CV_H128_3 && vb == CV_L64) rc = launch_pair<128, 3, 64, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H256_6 && vb == CV_L128) rc = launch_pair<256, 6, 64, 2, 128, 128, 3, 4, 2>(a, b, nb64, s);
     }
     if (rc == -2) {
@@ -2632,7 +2649,7 @@ extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
     if (!(d.transposed && d.N % G == 0 && d.N0 == d.N && d.C1 == 0 && !d.D1 && !d.bias && !d.rowvec && !d.resid && d.alpha == 1.0f)) return 0;
     const int cpg = d.N / G;
     if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
-    return halo_tile(d) == 64 ? 1 : 0;
+    return (halo_tile(d) == 64 || lin2_gn_tile(d)) ? 1 : 0;
 }
 extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G) {
     if (!desc_host || G <= 0) return 0;
@@ -2641,7 +2658,7 @@ extern "C" int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G) {
     if (!(!d.transposed && d.N % G == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.acc0 && d.ldd0 == d.N)) return 0;
     const int cpg = d.N / G;
     if (!(cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64)) return 0;
-    return halo_tile(d) == 64 ? 1 : 0;
+    return (halo_tile(d) == 64 || lin2_gn_tile(d)) ? 1 : 0;
 }
 extern "C" int mdm_gemm_plan(const mdm_gemm_desc* desc_host, int* splitk_out, int64_t* ws_bytes_out) {
     if (!splitk_out || !ws_bytes_out) { set_error("gemm_plan: null output"); return -1; }

@@ -524,26 +524,29 @@ def test_grouped_weight_gradients_match_self_contained_ones():
 
 
 @pytest.mark.parametrize("case", [(8, 8, 256, 256, True, False), (16, 4, 128, 256, True, True), (4, 8, 128, 64, False, False),
-                                  (8, 8, 512, 256, True, True), (4, 4, 2048, 64, True, False)])      # last: 64-channel groups -> 64-wide tiles
+                                  (8, 8, 512, 256, True, True), (4, 4, 2048, 64, True, False),       # 64-channel groups -> 64-wide tiles
+                                  (8, 8, 256, 768, False, False, 1), (16, 4, 256, 768, False, False, 1)])   # 1x1 convolutions (conv_lin2 tiles)
 def test_groupnorm_backward_fused_into_the_data_gradient(case):
     """4x4 / 8x8 maps: z = silu?(GroupNorm(x)) feeds a 3x3 conv; the conv's data gradient runs the GroupNorm backward in
     its epilogue (gnb_*): dx, dgamma, dbeta and the optional column sums against torch autograd."""
     from mdm import ops
     dt = "bf16"
-    N, H, C, Cout, silu, with_sums = case
+    N, H, C, Cout, silu, with_sums = case[:6]
+    ks = case[6] if len(case) > 6 else 3
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + C)
     x = _q(torch.randn(N, C, H, H, generator=g) * 1.2 + 0.3, dt).requires_grad_(True)
     gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
     beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
-    w = _q(torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5), dt)
+    w = _q(torch.randn(Cout, C, ks, ks, generator=g) / (ks * C ** 0.5), dt)
     z = F.group_norm(x, 32, gamma, beta, eps=1e-6)
     if silu:
         z = F.silu(z)
-    y = F.conv2d(z, w, None, padding=1)
+    y = F.conv2d(z, w, None, padding=ks // 2)
     gy = _q(torch.randn(y.shape, generator=g), dt)
     y.backward(gy)
     dev = _dev()
-    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
+    pd = ks // 2
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout, KH=ks, KW=ks, pad_t=pd, pad_l=pd, pad_b=pd, pad_r=pd)
     assert ops.conv_dgrad_t_can_fuse_gn_bwd(1, geom)
     xh = _up(_nhwc(x.detach()), dt)
     zb = torch.empty_like(xh); stats = torch.empty(N, 32, 2, device=dev)
@@ -573,27 +576,30 @@ def test_groupnorm_backward_fused_into_the_data_gradient(case):
 
 
 @pytest.mark.parametrize("case", [(8, 8, 128, 256, True), (16, 4, 256, 128, True), (4, 8, 64, 512, False),
-                                  (4, 4, 64, 2048, True)])                                          # last: 64-channel groups -> 64-wide tiles
+                                  (4, 4, 64, 2048, True),                                           # 64-channel groups -> 64-wide tiles
+                                  (8, 8, 256, 256, False, 1), (16, 4, 256, 256, True, 1)])          # 1x1 convolutions (conv_lin2 tiles)
 def test_groupnorm_forward_fused_into_the_producing_conv(case):
     """4x4 / 8x8 maps: the conv's epilogue (bias + time-embedding row + residual, bf16 store) also writes
     silu?(GroupNorm(y)) and the (mean, rstd) statistics (gnf_*)."""
     from mdm import ops
     dt = "bf16"
-    N, H, C, Cout, silu = case
+    N, H, C, Cout, silu = case[:5]
+    ks = case[5] if len(case) > 5 else 3
     g = torch.Generator().manual_seed(N * 100 + H + Cout)
     x = _q(torch.randn(N, C, H, H, generator=g), dt)
-    w = _q(torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5), dt)
+    w = _q(torch.randn(Cout, C, ks, ks, generator=g) / (ks * C ** 0.5), dt)
     b = torch.randn(Cout, generator=g)
     rv = torch.randn(N, Cout, generator=g)
     res = _q(torch.randn(N, Cout, H, H, generator=g), dt)
     gamma = 1 + 0.2 * torch.randn(Cout, generator=g)
     beta = 0.1 * torch.randn(Cout, generator=g)
-    y = _q(F.conv2d(x, w, b, padding=1) + rv[:, :, None, None] + res, dt)          # what a separate GroupNorm launch would read
+    y = _q(F.conv2d(x, w, b, padding=ks // 2) + rv[:, :, None, None] + res, dt)    # what a separate GroupNorm launch would read
     z = F.group_norm(y, 32, gamma, beta, eps=1e-6)
     if silu:
         z = F.silu(z)
     dev = _dev()
-    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout)
+    pd = ks // 2
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C, C1=0, Cout=Cout, KH=ks, KW=ks, pad_t=pd, pad_l=pd, pad_b=pd, pad_r=pd)
     out = torch.empty(N, H, H, Cout, device=dev, dtype=torch.bfloat16)
     zo = torch.empty_like(out); stats = torch.full((N, 32, 2), float("nan"), device=dev)
     ops.conv_fwd(1, geom, _up(_nhwc(x), dt), None, _up(_w_tap(w), dt), b.to(dev), out, rowvec=rv.to(dev), rv_ld=Cout,
