@@ -27,6 +27,11 @@ Extra objects in that line:
                host-replayed draws through the CPU oracle in the cpu_baseline child); the headline entry is the
                dtype that meets north_star's 1e-3.
 
+`--config cfg3|cfg4|cfg5` adds `extras[<name>]` (the headline line stays cfg2): the 64x64 base-trainer step at 8 images per
+GPU, the attention-everywhere 4-channel step at 16 images (L = 1024), the 250-step mean-shift sampler -- each with its step time
+and contraction-family TFLOP/s.  `--cut-graph` adds `extras["cut_graph"]`: the SAME step in the form a data-parallel rank runs
+it (front / bucket pieces / tail graphs instead of one graph, world = 1, no exchange), to price the cut on one GPU.
+
 `--gpus N` without torchrun's environment starts the N ranks itself (child `python -m torch.distributed.run`,
 before this process touches the GPU) and relays the JSON line; a line whose n_gpus != --gpus is never printed.
 """
@@ -72,7 +77,15 @@ def make_args(**kw):
     return a
 
 
-PARITY_N, PARITY_STRIDE, PARITY_SEED = 4, 50, 4321      # the sampler parity sample: 4 images, every 50th of the 1000 timesteps
+PARITY_N, PARITY_T, PARITY_SEED, PARITY_FREE = 2, 1000, 4321, 100
+# The sampler parity sample: PARITY_N images through ALL 1000 reverse steps of the schedule the timed run uses, host-replayed
+# draws, bench architecture with non-degenerate weights.  Two figures per dtype, both against oracle/sampler_ref.py (fp32):
+#   teacher-forced  every step starts from the oracle's x_t of that step (Sampler.step_hook); the worst and the median
+#                   rel-L2 of x0_hat over the 1000 steps -- the per-step error of the kernels at every t of the schedule;
+#   free-running    the LAST PARITY_FREE steps (t = 100 .. 1) as one contiguous run from the oracle's x_t at t = 100;
+#                   rel-L2 of the final sample.  (An untrained U-Net iterated 1000 times is a chaotic map: the oracle's
+#                   own fp32 run is O(1) away from its fp64 run by then -- tests/test_device_path_gpu.py records it --
+#                   so a free run over the whole schedule would measure conditioning, not the kernels.)
 
 
 def parity_params(shapes, seed=77):
@@ -102,16 +115,16 @@ def _seed_host(s):
 
 
 def parity_args():
-    return make_args(rng_mode="replay", sample_num=PARITY_N, sample_latent_shape="uniform", sample_history=False)
+    return make_args(rng_mode="replay", sample_num=PARITY_N, sample_latent_shape="uniform", sample_history="device")
 
 
-def cpu_baseline(n_steps=10, n_warm=2, parity_file=None):
-    """CPU child: time the oracle's train step (and a bounded sample of its reverse sampler) on the same
-    workload shape (fp32, the box's host cores); check the GPU sampler's parity sample against the oracle."""
+def cpu_baseline(n_steps=10, n_warm=2, parity_out=None):
+    """CPU child: time the oracle's train step (and its reverse sampler) on the same workload shape (fp32, the box's host
+    cores); leave the oracle's 1000-step sampler trajectory in `parity_out` for the GPU parent to check itself against."""
     import statistics
 
     import numpy as np
-    from oracle.sampler_ref import SamplerRef
+    from oracle.sampler_ref import HISTORY_NAMES, SamplerRef
     from oracle.scheduler_ref import SchedulerRef
     from oracle.trainer_ref import train_step_ref
     from oracle.unet_ref import UNetRef, param_shapes, unet6_config
@@ -146,26 +159,156 @@ def cpu_baseline(n_steps=10, n_warm=2, parity_file=None):
     out = {"value": round(32 / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
            "sample": f"median of {n_steps} optimisation steps of 32x3x32x32 after {n_warm} warm-up steps "
                      f"(oracle/trainer_ref.py, fp32); step times min/median/max {min(times):.3f}/{med:.3f}/{max(times):.3f} s"}
-    # ---- the reverse sampler on the CPU: the parity sample's loop (PARITY_N images, every PARITY_STRIDE-th timestep)
+    # ---- the reverse sampler on the CPU: PARITY_N images through the whole 1000-step schedule (also the parity trajectory)
     pa = parity_args()
     ps = SchedulerRef(pa)
     ps.update_ddpm_num_steps(1000)
-    ts = ps.get_timesteps_epoch(0, 1)[PARITY_STRIDE - 1::PARITY_STRIDE]
+    ts = ps.get_timesteps_epoch(0, 1)
     pm = UNetRef(cfg, parity_params(param_shapes(cfg)))
     _seed_host(PARITY_SEED)
     t0 = time.perf_counter()
-    want, _ = SamplerRef(None, pa, ps, [None] * 3).sample(pm, ts)
+    want, hist = SamplerRef(None, pa, ps, [None] * 3).sample(pm, ts)
     sec = time.perf_counter() - t0
     per_img_step = sec / (len(ts) * PARITY_N)
     out["sampler"] = {"seconds_per_reverse_step_per_image": round(per_img_step, 5), "cores": cores,
                       "estimate_1000_steps_x100_seconds": round(per_img_step * 1000 * 100, 1),
                       "sample": f"{len(ts)} reverse steps x {PARITY_N} images timed ({sec:.2f} s, oracle/sampler_ref.py fp32, history on); "
                                 "the 1000-step x sample_num=100 figure is that per-step-per-image time x 1e5 (an estimate, not a run)"}
-    log(f"cpu baseline: sampler sample {sec:.2f}s")
-    if parity_file and os.path.exists(parity_file):
-        z = np.load(parity_file)
-        w = want.double().numpy()
-        out["sampler_parity"] = {k: float(np.linalg.norm(z[k].astype(np.float64) - w) / np.linalg.norm(w)) for k in z.files}
+    log(f"cpu baseline: sampler {len(ts)} steps x {PARITY_N} images {sec:.2f}s")
+    if parity_out:
+        h = dict(zip(HISTORY_NAMES, hist))
+        np.savez(parity_out, sample_t=h["sample_t"].numpy(), sample_0=h["sample_0"].numpy(), x0=want.numpy())
+    return out
+
+
+def sampler_parity(mdm, cfg, sdt, dev, pparams, ref):
+    """-> dict of the two parity figures (see PARITY_*) for one dtype; `ref` = the oracle child's trajectory (numpy)."""
+    pa = parity_args()
+    net = mdm.UNet(cfg, N=PARITY_N, H=32, W=32, dtype=sdt, params=pparams, use_graph=False).eval()
+    sch = mdm.Scheduler(pa, device=dev)
+    sch.update_ddpm_num_steps(PARITY_T)
+    ts = sch.get_timesteps_epoch(0, 1)
+    ref_xt = torch.from_numpy(ref["sample_t"]).to(dev)
+    ref_x0h = torch.from_numpy(ref["sample_0"]).to(dev).double()
+    smp = mdm.Sampler(None, pa, sch, [None] * 3)
+    smp.step_hook = lambda i, slot, x_t: x_t.copy_(ref_xt[slot])
+    _seed_host(PARITY_SEED)
+    _, hist = smp.sample(net, ts)
+    got = hist[mdm.sampler.HISTORY_NAMES.index("sample_0")].double()
+    e = ((got[1:] - ref_x0h[1:]).flatten(1).norm(dim=1) / ref_x0h[1:].flatten(1).norm(dim=1))
+    out = {"teacher_forced_steps": PARITY_T, "teacher_forced_worst": float(e.max()), "teacher_forced_median": float(e.median())}
+    # free-running over the last PARITY_FREE steps: the host RNG must stand where the oracle's stood at that step, so the
+    # loop is run from the top with the hook forcing x_t up to the hand-over step and leaving it alone afterwards
+    pa2 = parity_args()
+    pa2.sample_history = False
+    smp2 = mdm.Sampler(None, pa2, sch, [None] * 3)
+    smp2.step_hook = lambda i, slot, x_t: x_t.copy_(ref_xt[slot]) if i >= PARITY_FREE - 1 else None
+    _seed_host(PARITY_SEED)
+    x0, _ = smp2.sample(net, ts)
+    w = torch.from_numpy(ref["x0"]).to(dev).double()
+    out["free_running_last_steps"] = PARITY_FREE
+    out["free_running_rel_l2"] = float((x0.double() - w).norm() / w.norm())
+    del net
+    return out
+
+
+def time_steps(step, used, warmup, steps):
+    for _ in range(warmup):
+        step.run_device(None, used)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.run_device(None, used)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def family_roofline(_lib, step, model, optim, ema, dt, reps=3):
+    """HIP events around every contraction launch of the step (see `roofline` in the module docstring) ->
+    (TFLOP/s, ms per step in the family, launches per step, event-pair cost in ms)."""
+    st = torch.cuda.current_stream().cuda_stream
+    with _lib.Recording() as front:
+        step._emit_device_front()
+    pick = lambda rec: (lambda i, name: (name in ("mdm_gemm", "mdm_gemm_pair") and rec.flops.get(i, (0, -1))[1] == dt) or
+                        name == "mdm_wgrad_group_launch")
+    tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
+    step._hyper()
+    front.run(st)
+    pair_ms = front.event_overhead(st, pick(front))
+    for _ in range(reps):
+        step._hyper()
+        for rec in (front, model.backward_plan):
+            for i, ms in rec.run_timed(st, pick(rec), pair_ms):
+                tot_ms += ms
+                if i in rec.flops:
+                    tot_fl += rec.flops[i][0]
+                    n_launch += 1
+        optim.emit_update(ema.shadow if ema is not None else None, 1.0, 1.0)
+    torch.cuda.synchronize()
+    return tot_fl / (tot_ms * 1e-3) / 1e12, tot_ms / reps, n_launch // reps, pair_ms, tot_fl / reps
+
+
+def bench_cut_graph(mdm, TrainStep, model, sched, args, optim, ema, used, opt_, whole_ms):
+    """The step as a data-parallel rank runs it -- front graph, one graph per gradient bucket, tail graph, the bucket hooks
+    firing with world = 1 -- next to the one-graph form, same model, same box, back to back."""
+    a2 = argparse.Namespace(**vars(args))
+    a2.cut_step_graph = True
+    cut = TrainStep(model, sched, a2, optim, ema, mean_shift=True, comm=None)
+    cut.x0.copy_(torch.rand(model.N, 3, model.H, model.W) * 2 - 1)
+    ms = time_steps(cut, used, opt_.warmup, opt_.steps)
+    pieces = len(cut._graphs[2]) + (1 if cut._graphs[3] is not None else 0)
+    log(f"cut-graph form: {ms:.4f} ms/step in {pieces} backward pieces (+ front + tail) vs {whole_ms:.4f} whole")
+    return {"ms_per_step": round(ms, 4), "whole_graph_ms_per_step": round(whole_ms, 4), "ratio": round(ms / whole_ms, 4),
+            "graphs_per_step": pieces + 2, "note": "front / bucket pieces / tail hipGraphs, bucket hooks with world = 1 (no exchange)"}
+
+
+def bench_config(mdm, _lib, TrainStep, name, dev, opt_):
+    """One of BASELINE.json's other configurations on this GPU: step time, family TFLOP/s; cfg5: the 250-step sampler."""
+    from mdm.unet import unet6_config
+    dt = mdm.BF16
+    if name == "cfg3":          # 64x3x64x64, base trainer (trainer_masked.py), 8 images per GPU (global 64 over DP=8)
+        N, H, cfg, mean_shift, flops_img = 8, 64, unet6_config(64), False, 140.19e9
+        a = make_args(batch_size=N, data_size=64, shift_type="non_shift", seed=77)
+        what = "BASELINE.json configs[2]: 64x3x64x64, unet6 preset, base trainer (non_shift), 8 images per GPU"
+    elif name == "cfg4":        # 16x4x32x32, attention at every level (models_Unet.py:146 alternative): L = 1024 .. 16
+        N, H, mean_shift, flops_img = 16, 32, False, 48.10e9
+        cfg = dict(in_channels=4, hid_channels=128, out_channels=4, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2, apply_attn=[True] * 4)
+        a = make_args(batch_size=N, data_size=32, in_channel=4, out_channel=4, shift_type="non_shift", seed=78)
+        what = "BASELINE.json configs[3]: 16x4x32x32, unet6 with attention at all four levels (L = 1024, 256, 64, 16), base trainer"
+    else:                       # cfg5: mean-shift trainer + 250-step reverse sampler, sample_num 100
+        N, H, cfg, mean_shift, flops_img = 32, 32, unet6_config(32), True, 34.87e9
+        a = make_args(batch_size=N, ddpm_num_steps=250, seed=79)
+        what = "BASELINE.json configs[4]: mean-shift trainer (32x3x32x32) + 250-step reverse sampler, sample_num 100, bf16"
+    C = cfg["in_channels"]
+    model = mdm.UNet(cfg, N=N, H=H, W=H, dtype=dt, seed=0)
+    optim = mdm.AdamW(model, lr=1e-4)
+    ema = mdm.EMA(model)
+    sched = mdm.Scheduler(a, device=dev)
+    sched.update_ddpm_num_steps(a.ddpm_num_steps)
+    used = sched.get_timesteps_epoch(0, 1)
+    step = TrainStep(model, sched, a, optim, ema, mean_shift=mean_shift)
+    step.x0.copy_(torch.rand(N, C, H, H) * 2 - 1)
+    ms = time_steps(step, used, opt_.warmup, opt_.steps)
+    tf, fam_ms, n_launch, pair_ms, fl = family_roofline(_lib, step, model, optim, ema, dt)
+    out = {"workload": what, "ms_per_step": round(ms, 4), "images_per_s": round(N / (ms * 1e-3), 1), "per_gpu_batch": N,
+           "params": model.num_parameters(), "tflops_step": round(flops_img * N / (ms * 1e-3) / 1e12, 1),
+           "family": {"achieved_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "kernel_ms_per_step": round(fam_ms, 3),
+                      "launches_per_step": n_launch, "flops_per_step": fl, "event_pair_us": round(1e3 * pair_ms, 2)},
+           "launches": {"forward": len(model.forward_plan.calls), "backward": len(model.backward_plan.calls)}}
+    log(f"{name}: {ms:.3f} ms/step, family {tf:.0f} TFLOP/s")
+    if name == "cfg5":
+        a.sample_num = 100
+        for tag, sdt in (("bf16", mdm.BF16), ("f32", mdm.F32)):
+            net = (model.with_batch(100) if sdt == dt else mdm.UNet(cfg, N=100, H=H, W=H, dtype=sdt, seed=0)).eval()
+            smp = mdm.Sampler(None, a, sched, [None] * 3)
+            smp.sample(net, used[:3])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            x0, _ = smp.sample(net, used)
+            torch.cuda.synchronize()
+            out[f"sampler_{tag}"] = {"steps": len(used), "sample_num": 100, "seconds": round(time.perf_counter() - t1, 3),
+                                     "finite": bool(torch.isfinite(x0).all())}
+            del net
     return out
 
 
@@ -182,14 +325,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-timed replay (kernel-count profiles: every profiled launch then belongs to a whole step)")
     ap.add_argument("--wgrad-group-mb", type=float, default=None, help=argparse.SUPPRESS)      # experiments only
-    ap.add_argument("--overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--config", action="append", default=[], choices=["cfg3", "cfg4", "cfg5"],
+                    help="also measure this BASELINE.json configuration (reported under `extras`; the headline stays cfg2)")
+    ap.add_argument("--cut-graph", action="store_true", help="also time the data-parallel (cut) form of the step graph on this one GPU")
     ap.add_argument("--no-pair", action="store_true", help=argparse.SUPPRESS)                  # experiments only: every convolution its own launch
     ap.add_argument("--grad-wire", default="f32", choices=["f32", "bf16"], help="dtype of the gradient all-reduce payload (N > 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--parity-file", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--parity-out", default=None, help=argparse.SUPPRESS)
     opt_ = ap.parse_args()
     if opt_.cpu_baseline_only:           # child process of the cpu_baseline leg: CPU only, never touches the GPU
-        print(json.dumps(cpu_baseline(parity_file=opt_.parity_file)))
+        print(json.dumps(cpu_baseline(parity_out=opt_.parity_out)))
         return
     if "WORLD_SIZE" not in os.environ and opt_.gpus > 1:
         # `python bench.py --gpus N`: start the N ranks ourselves, one per GPU, BEFORE anything here touches the GPU
@@ -225,7 +370,7 @@ def main():
     dev = torch.device("cuda", local)
     dt = mdm.BF16 if opt_.dtype == "bf16" else mdm.F32
     N = opt_.batch
-    args = make_args(batch_size=N, seed=1234 + rank, use_graph=not opt_.no_graph, overlap_wgrads=opt_.overlap)   # per-rank RNG streams
+    args = make_args(batch_size=N, seed=1234 + rank, use_graph=not opt_.no_graph)   # per-rank RNG streams
 
     cfg = mdm.unet6_config(32)
     xk = {}
@@ -333,23 +478,47 @@ def main():
                     "census": {"a_out": a_census, "algorithmic_bytes": b_census, "frac": round(gbs(b_census) / PEAK_HBM_GBS, 4)},
                     "flops_per_step": 34.87e9 * N, "tflops": round(34.87e9 * N / (ms_per_step * 1e-3) / 1e12, 1)}
 
-    # ---- 1k-step sampler wall-clock (single GPU: samples are independent, no collective; N>1 shards sample_num)
-    sampler = None
+    # ---- CPU baseline leg first (bounded child process, own thread pool, no GPU context): it also leaves the oracle's
+    # 1000-step sampler trajectory behind, which the sampler parity sample below is checked against
+    cpu = None
     parity_file = None
-    if rank == 0 and world == 1 and not opt_.no_sampler:
+    ref = None
+    if rank == 0 and world == 1 and not opt_.no_cpu_baseline:
+        import subprocess
         import tempfile
 
         import numpy as np
+        try:
+            env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
+            if not opt_.no_sampler:
+                fd, parity_file = tempfile.mkstemp(suffix=".npz", prefix="mdm_parity_")
+                os.close(fd)
+                cmd += ["--parity-out", parity_file]
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            sys.stderr.write(r.stderr)
+            cpu = json.loads(r.stdout.strip().splitlines()[-1])
+            if parity_file:
+                ref = dict(np.load(parity_file))
+        except Exception as e:          # never let the baseline leg take the bench line down
+            cpu = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:200]}
+        finally:
+            if parity_file:
+                try:
+                    os.unlink(parity_file)
+                except OSError:
+                    pass
+
+    # ---- 1k-step sampler wall-clock (single GPU: samples are independent, no collective; N>1 shards sample_num)
+    sampler = None
+    if rank == 0 and world == 1 and not opt_.no_sampler:
         sampler = {}
-        par = {}
-        pshapes = model.reference_shapes()
-        pparams = parity_params(pshapes)
+        pparams = parity_params(model.reference_shapes())
         for tag, sdt in (("f32", mdm.F32), ("bf16", mdm.BF16)):
             if sdt == dt:
                 net = model.with_batch(args.sample_num).eval()
             else:
-                base = mdm.UNet(cfg, N=args.sample_num, H=32, W=32, dtype=sdt, seed=0, use_graph=not opt_.no_graph)
-                net = base.eval()
+                net = mdm.UNet(cfg, N=args.sample_num, H=32, W=32, dtype=sdt, seed=0, use_graph=not opt_.no_graph).eval()
             smp = mdm.Sampler(None, args, sched, [None] * 3)
             smp.sample(net, used[:3])                            # warm-up / graph capture
             torch.cuda.synchronize()
@@ -361,51 +530,34 @@ def main():
             log(f"sampler {tag}: {sec:.2f}s")
             sampler[tag] = {"dtype": tag, "steps": nst, "sample_num": args.sample_num, "seconds": round(sec, 3),
                             "ms_per_step": round(1e3 * sec / nst, 3), "finite": bool(torch.isfinite(x0_hat).all())}
-            # parity sample: same kernels, non-degenerate weights, the reference's host draws replayed
-            pa = parity_args()
-            pnet = mdm.UNet(cfg, N=PARITY_N, H=32, W=32, dtype=sdt, params=pparams, use_graph=False).eval()
-            psch = mdm.Scheduler(pa, device=dev)
-            psch.update_ddpm_num_steps(1000)
-            pts = psch.get_timesteps_epoch(0, 1)[PARITY_STRIDE - 1::PARITY_STRIDE]
-            _seed_host(PARITY_SEED)
-            px0, _ = mdm.Sampler(None, pa, psch, [None] * 3).sample(pnet, pts)
-            torch.cuda.synchronize()
-            par[tag] = px0.cpu().numpy()
-            del pnet, net
-        fd, parity_file = tempfile.mkstemp(suffix=".npz", prefix="mdm_parity_")
-        os.close(fd)
-        np.savez(parity_file, **par)
-
-    cpu = None
-    if rank == 0 and world == 1 and not opt_.no_cpu_baseline:
-        # bounded: a child process (its own torch thread pool, no GPU context) with a hard time limit
-        import subprocess
-        try:
-            env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"]
-            if parity_file:
-                cmd += ["--parity-file", parity_file]
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
-            sys.stderr.write(r.stderr)
-            cpu = json.loads(r.stdout.strip().splitlines()[-1])
-        except Exception as e:          # never let the baseline leg take the bench line down
-            cpu = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:200]}
-    if parity_file:
-        try:
-            os.unlink(parity_file)
-        except OSError:
-            pass
-    if sampler:
-        # rel-L2 of the GPU sampler's parity sample against the CPU oracle (computed by the cpu_baseline child), per dtype;
-        # the headline entry is the fastest dtype that meets north_star's 1e-3 (fp32 when none does: say so)
-        rels = (cpu or {}).pop("sampler_parity", {}) if isinstance(cpu, dict) else {}
-        for tag in sampler:
-            sampler[tag]["rel_l2_vs_oracle"] = rels.get(tag)
-            sampler[tag]["parity_sample"] = (f"{PARITY_N} images x {1000 // PARITY_STRIDE} reverse steps (every {PARITY_STRIDE}th timestep) of the bench "
-                                             "architecture with non-degenerate random weights, host-replayed draws, vs oracle/sampler_ref.py fp32")
+            del net
+            par = None
+            if ref is not None:
+                try:
+                    par = sampler_parity(mdm, cfg, sdt, dev, pparams, ref)
+                    log(f"sampler parity {tag}: {par}")
+                except Exception as e:      # noqa: BLE001
+                    par = {"error": f"{type(e).__name__}: {e}"[:200]}
+            sampler[tag]["parity"] = par
+            # the figure the 1e-3 claim is made on: the contiguous free run over the last PARITY_FREE steps of the schedule,
+            # and nothing worse than that at any single step of the 1000
+            sampler[tag]["rel_l2_vs_oracle"] = None if not par or "error" in par else max(par["free_running_rel_l2"], par["teacher_forced_worst"])
+            sampler[tag]["parity_sample"] = (f"{PARITY_N} images, bench architecture with non-degenerate random weights, host-replayed draws, vs "
+                                             f"oracle/sampler_ref.py fp32: max of (a) the worst per-step rel-L2 of x0_hat over all {PARITY_T} reverse "
+                                             f"steps, each started from the oracle's x_t (teacher forcing), and (b) the rel-L2 of the final sample of "
+                                             f"a contiguous free run over the last {PARITY_FREE} steps")
         ok = [t for t in ("bf16", "f32") if sampler[t]["rel_l2_vs_oracle"] is not None and sampler[t]["rel_l2_vs_oracle"] < 1e-3]
         head = min(ok, key=lambda t: sampler[t]["seconds"]) if ok else "f32"
         sampler = {**sampler[head], "meets_1e-3": bool(ok), "by_dtype": sampler}
+
+    # ---- extras: the cut (data-parallel) form of the step on this one GPU; the other BASELINE configurations
+    extras = {}
+    if rank == 0 and world == 1 and opt_.cut_graph:
+        extras["cut_graph"] = bench_cut_graph(mdm, TrainStep, model, sched, args, optim, ema, used, opt_, ms_per_step)
+    if rank == 0 and world == 1:
+        for name in opt_.config:
+            log(f"extra configuration {name}")
+            extras[name] = bench_config(mdm, _lib, TrainStep, name, dev, opt_)
 
     if rank == 0:
         out = {
@@ -420,6 +572,8 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
             "roofline": roofline, "step_hbm": step_hbm, "cpu_baseline": cpu, "sampler": sampler,
         }
+        if extras:
+            out["extras"] = extras
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -88,8 +88,9 @@ typedef struct mdm_gemm_desc {
     int64_t dtap;               /* layout 2 + conv: D0 offset per tap */
     /* split-K workspace (optional).  With it, every split writes its fp32 partial tile with plain
      * stores into ws[split][tap|batch][M][N] and a second kernel sums the splits into D0 -- float
-     * atomics from dozens of workgroups into one tile serialise at the memory side.  Without it
-     * (or when D0 is not a dense [tap|batch][M][N] block) split-K falls back to fp32 atomics. */
+     * atomics from dozens of workgroups into one tile serialise at the memory side AND sum in arrival
+     * order.  Without it (or when D0 is not a dense [tap|batch][M][N] block) the reduction is not
+     * split: there is no atomic fallback, results do not depend on scheduling. */
     void* ws; int64_t ws_bytes;
     /* layout 2, bf16: if set, dbias[m] += sum_k A[k][m] (the bias gradient of a convolution is the column
      * sum of dY, which the weight-gradient kernel already holds as MFMA fragments: one extra MFMA against
@@ -267,11 +268,12 @@ int mdm_nhwc_to_nchw(int dtype, const void* x, float* y, int N, int C, int H, in
 /* On-device draw of the per-sample step (trainer_masked_mean_shift.py:109-112,
  * scheduler.py:88-100, 780-794): idx ~ U{0..n_used-1}; t = used[idx]; amount = table[t-1];
  * weight = wtab[idx] (or 1); out2 = table2[t-1] for a second schedule table (the shift ratio; both may be NULL);
- * *zero_out = 0 (may be NULL: the loss accumulator mdm_loss_fwd_bwd adds to -- this is the first launch of a step).
+ * zero_out[0] = zero_out[1] = 0 (may be NULL: the two-word loss accumulator mdm_loss_fwd_bwd adds to -- this is the first
+ * launch of a step).
  * Philox4x32-10 keyed by rng[0]=seed, rng[1]=offset (device memory). */
 int mdm_draw_timesteps(const uint64_t* rng, const int32_t* used, int n_used, const double* table,
                        const float* wtab, int N, float* t_out, double* amount_out, float* weight_out,
-                       int32_t* idx_out, const double* table2, double* out2, float* zero_out, void* stream);
+                       int32_t* idx_out, const double* table2, double* out2, int64_t* zero_out, void* stream);
 
 /* Thresholding mask + fill + degrade (scheduler.py:286-323 == 438-477 == 572-598).
  *   u: [N][Cm*HW] uniforms (replay mode) or NULL (device Philox, stream id `rng_stream`);
@@ -301,13 +303,21 @@ int mdm_index_mask(const double* count, int count_stride, const uint64_t* rng, i
 int mdm_shift(const float* x_t, const float* z, const double* ratio, const uint64_t* rng, int rng_stream,
               int kind, float noise_mean, int per_column, int N, int C, int H, int W,
               float* s, float* x_in, int dtype, void* x_in_nhwc, int Cp, void* stream);
+/* x_nhwc[pix][C .. Cp) = 0 for npix pixels: what a caller that did not get its buffer from a zeroing allocator runs ONCE
+ * before the first mdm_shift on it (mdm_shift leaves the pad channels alone; the first convolution multiplies them by zero
+ * weights, so garbage there -- a NaN -- would poison its output and its weight gradient). */
+int mdm_zero_pad_channels(int dtype, void* x_nhwc, int64_t npix, int C, int Cp, void* stream);
 
 /* Fused x0-space loss + its gradient (trainer_masked_mean_shift.py:142-159, trainer_masked.py:126-140):
  *   r = (x_in + pred) - s - x0 ;  loss += sum(w_n * r^2) / numel ;  dpred = 2 w_n r / numel * gscale
- * pred, dpred: NHWC dtype with Cp channels (pad channels of dpred are written 0). s, w may be NULL. */
+ * pred, dpred: NHWC dtype with Cp channels (pad channels of dpred are written 0). s, w may be NULL.
+ * loss_q40: TWO int64 words the caller zeroes before a step (mdm_draw_timesteps does).  [0] += the loss in Q23.40 fixed
+ * point (loss = (double)loss_q40[0] * 2^-40): the workgroups' partial sums meet through INTEGER atomics, which commute, so
+ * the value is bit-identical from run to run (a float atomic sums in arrival order).  [1] counts partials that were not
+ * finite or >= 2^22: non-zero means the loss is not representable (report NaN). */
 int mdm_loss_fwd_bwd(int dtype, const void* pred, const float* x_in, const float* s, const float* x0,
                      const float* w, int N, int C, int H, int W, int Cp, float gscale,
-                     void* dpred, float* loss_accum, void* stream);
+                     void* dpred, int64_t* loss_q40, void* stream);
 
 /* Reverse-step pieces (sampler.py:146-152, 199-216):
  *   x0_hat = (x_in + pred) - s                                              (mdm_sampler_x0)

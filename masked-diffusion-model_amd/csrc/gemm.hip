@@ -173,10 +173,7 @@ __device__ __forceinline__ void epilogue4(const mdm_gemm_desc& d, const ZInfo& z
     if (d.splitk > 1 && d.ws) {          // partial slab [split][tap|batch][M][N], plain stores; summed by splitk_reduce_kernel
         float* p = reinterpret_cast<float*>(d.ws) + ((int64_t)z.ks * z.nouter + z.outer) * ((int64_t)d.M * d.N) + (int64_t)m * d.N + n;
         store4(p, v);
-    } else if (d.splitk > 1) {
-        float* p = reinterpret_cast<float*>(base) + off;
-        atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
-    } else if (d.out_f32) {
+    } else if (d.out_f32) {        // (a split reduction never lands here: without a workspace resolve() does not split)
         float* p = reinterpret_cast<float*>(base) + off;
         if (acc) { float4 o = load4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         store4(p, v);
@@ -484,13 +481,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
             if (n < d.N) epilogue4<float>(d, z, m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
         }
     }
-    // bias gradient of a linear layer next to its weight gradient (layout 2, no gather): dbias[m] += sum_k A[k][m] over this
-    // workgroup's k-range, by the workgroups of the first column tile -- the k-rows are few (the batch) and just went through L2
-    if (LAYOUT == 2 && d.dbias && !d.conv && n0 == 0 && t < BM && m0 + t < d.M) {
+    // bias gradient of a linear layer next to its weight gradient (layout 2, no gather): dbias[m] += sum_k A[k][m] over the
+    // WHOLE reduction, by the workgroups of the first column tile of the first k-range -- one writer per element and a fixed
+    // order (the fp32 path is bit-reproducible); the k-rows are few (the batch) and just went through L2
+    if (LAYOUT == 2 && d.dbias && !d.conv && n0 == 0 && blockIdx.z == 0 && t < BM && m0 + t < d.M) {
         float sum = 0.f;
-        const float* p = reinterpret_cast<const float*>(d.A) + z.batch * d.sA + m0 + t;
-        for (int k = z.kbeg; k < z.kend; ++k) sum += p[(int64_t)k * d.lda];
-        atomicAdd(&d.dbias[m0 + t], sum);
+        const float* p = reinterpret_cast<const float*>(d.A) + m0 + t;
+        for (int k = 0; k < d.K; ++k) sum += p[(int64_t)k * d.lda];
+        d.dbias[m0 + t] += sum;
     }
 }
 
@@ -1263,14 +1261,16 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
         atomicAdd(which ? d.gnb_dbeta + n0 + c : d.gnb_dgamma + n0 + c, v);
     }
     const int ppi = P >> 4, nimg = 64 >> p_sh;          // parts per image (1 or 4), images per tile
-    if (t < nimg * BN) {                 // group sums per image: (image il2, channel c) -> gs[il2][group][0/1]
-        const int il2 = t / BN, c = t - il2 * BN;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const int col = (8 * w + (c & 7)) * NCH + (c >> 3);
+    {                                    // group sums per image: thread (image il2, group gl, w) walks its channels in order
+        const int ngt_sh = (BN == 64 ? 6 : 5) - cpg_sh, ngt = 1 << ngt_sh;          // groups inside this BN-channel tile
+        if (t < nimg * ngt * 2) {        // (it was an LDS float atomic per channel: sums in arrival order are not reproducible)
+            const int w = t & 1, gl = (t >> 1) & (ngt - 1), il2 = t >> (1 + ngt_sh);
             float v = 0.f;
-            for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
-            atomicAdd(&gs[(il2 * 16 + (c >> cpg_sh)) * 2 + w], v);
+            for (int j = 0; j < cpg; ++j) {
+                const int c = (gl << cpg_sh) + j, col = (8 * w + (c & 7)) * NCH + (c >> 3);
+                for (int pp = 0; pp < ppi; ++pp) v += psum[col * 4 + il2 * ppi + pp];
+            }
+            gs[(il2 * 16 + gl) * 2 + w] = v;
         }
     }
     __syncthreads();
@@ -1396,11 +1396,17 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
             psum[t] = sum;
         }
         __syncthreads();
-        if (t < nimg * BN) {
-            const int il2 = t / BN, c = t - il2 * BN, col = (c & 7) * NCH + (c >> 3);
-            float s2 = 0.f;
-            for (int pp = 0; pp < ppi; ++pp) s2 += psum[col * 4 + il2 * ppi + pp];
-            atomicAdd(&gs[il2 * 16 + (c >> cpg_sh)], s2);
+        {                                // thread (image il2, group gl) walks its channels in order (fixed summation order)
+            const int ngt_sh = (BN == 64 ? 6 : 5) - cpg_sh, ngt2 = 1 << ngt_sh;
+            if (t < nimg * ngt2) {
+                const int gl = t & (ngt2 - 1), il2 = t >> ngt_sh;
+                float s2 = 0.f;
+                for (int j = 0; j < cpg; ++j) {
+                    const int c = (gl << cpg_sh) + j, col = (c & 7) * NCH + (c >> 3);
+                    for (int pp = 0; pp < ppi; ++pp) s2 += psum[col * 4 + il2 * ppi + pp];
+                }
+                gs[il2 * 16 + gl] = s2;
+            }
         }
         __syncthreads();
         if (t < 64) {
@@ -2449,7 +2455,7 @@ static int resolve(const mdm_gemm_desc* dh, bool planning, Resolved& r) {
     }
     // slab mode needs a dense fp32 [tap|batch][M][N] destination and room for every split
     r.tap_split = d.conv && d.layout != 2 && d.splitk > 1;
-    const bool dense = d.out_f32 && d.N0 == d.N && d.ldd0 == d.N &&
+    const bool dense = (d.out_f32 || d.dtype == MDM_F32) && d.N0 == d.N && d.ldd0 == d.N &&
                        (d.layout == 2 && d.conv ? d.dtap == (int64_t)d.M * d.N : (r.zouter == 1 || d.sD == (int64_t)d.M * d.N));
     r.slab = (int64_t)r.zouter * d.M * d.N * 4;
     if (r.tap_split) {
@@ -2457,7 +2463,10 @@ static int resolve(const mdm_gemm_desc* dh, bool planning, Resolved& r) {
     } else if (d.splitk > 1 && d.ws && dense && d.ws_bytes >= r.slab * 2) {
         if (d.ws_bytes < r.slab * d.splitk) d.splitk = (int)(d.ws_bytes / r.slab);
     } else {
+        // no (usable) workspace: the reduction is not split.  (Round 1-2 fell back to float atomics on D here; summation in
+        // arrival order is not reproducible, and nothing on the product path needs it: every caller passes a workspace.)
         d.ws = nullptr;
+        d.splitk = 1;
     }
     return 0;
 }

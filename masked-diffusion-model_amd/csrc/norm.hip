@@ -1,6 +1,8 @@
 // GroupNorm(32)+SiLU forward/backward, row softmax, column sums, 2x2 sum-pool,
 // NCHW<->NHWC converters.  All HBM-bound streaming kernels over NHWC with 16-byte
-// vectors (8 channels) per lane; reductions are wave-shuffle + LDS + fp32 atomics.
+// vectors (8 channels) per lane.  Reductions inside a workgroup have a FIXED order (LDS column sums, one thread per
+// group); across workgroups the fp32 path goes through per-image partials + a second stage (bit-reproducible), the
+// bf16 path through one float atomic per channel per image.
 //
 // Replaces nn.GroupNorm / nn.SiLU (reference unet6.py:288-293, 358-360), torch.softmax
 // (unet6.py:320-322), nn.Upsample backward (unet6.py:472), and the bias / time-embedding
@@ -29,6 +31,54 @@ __device__ __forceinline__ float gn_pivot(const T* s0, const T* s1, int C0, int 
 }
 #define F8_TO_ARR(v) {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w}
 
+// Sum over the lanes of a wave that own the same channel vector (lane ids congruent mod VB, VB a power of two):
+// butterfly over the offsets VB, 2VB, ... 32.  Afterwards lanes 0..VB-1 hold the wave's totals, and only those
+// touch LDS -- 64 lanes adding to one LDS address with ds_add_f32 would serialise completely.
+// ---- workgroup column sums through LDS.  Every thread holds K partial values; thread t belongs to column
+// v = t % VB (its 8-channel vector) and the sums run over the 256/VB pixel lanes of each column.
+// (The first version reduced with __shfl_xor: 4 ds_bpermute round trips per value, 128 per thread in the
+// backward -- 20k cycles of a 36k-cycle kernel.)  scratch: K * CS_PITCH floats; out[k * VB + v].
+template <int K, int NT = 256>
+__device__ __forceinline__ void block_colsum(const float (&val)[K], float* scratch, float* out, int t, int VB, int PL) {
+    constexpr int CS_PITCH = NT + 4;
+#pragma unroll
+    for (int k = 0; k < K; ++k) scratch[k * CS_PITCH + t] = val[k];
+    __syncthreads();
+    const int cols = K * VB;                       // <= 256
+    int tpc = 1, tpc_sh = 0;                       // threads per column (power of two)
+    while (tpc * 2 * cols <= NT) { tpc *= 2; ++tpc_sh; }
+    const int col = t >> tpc_sh, part = t - (col << tpc_sh);
+    float sum = 0.f;
+    if (col < cols) {
+        const int k = div_small(col, rcp_small(VB)), v = col - k * VB;
+        // the tpc threads of a column take the pixel lanes INTERLEAVED (l = part, part + tpc, ...): neighbouring lanes then
+        // read neighbouring LDS words.  (Contiguous shares put the threads of a column a multiple of 64 words apart --
+        // 8-way bank conflicts, 62 % of the GroupNorm kernels' LDS cycles by SQ_LDS_BANK_CONFLICT.)
+        const float* src = scratch + k * CS_PITCH + v;
+        for (int l = part; l < PL; l += tpc) sum += src[l * VB];
+    }
+    for (int o = 1; o < tpc; o <<= 1) sum += __shfl_xor(sum, o, 64);     // <= 3 steps on ONE value
+    if (col < cols && part == 0) out[col] = sum;
+    __syncthreads();
+}
+
+// out[w] = sum over the `cpg` consecutive channels lc0 .. lc0+cpg-1 (local to the workgroup's channel block) of quantity w of
+// block_colsum's output: quantity w of channel lc sits at csum[(w * qstride + (lc & 7)) * VB + (lc >> 3)].
+// One thread, ascending channel order.
+template <int NQ>
+__device__ __forceinline__ void group_sums(const float* csum, int VB, int lc0, int cpg, int qstride, float* out) {
+    float a[NQ];
+#pragma unroll
+    for (int w = 0; w < NQ; ++w) a[w] = 0.f;
+    for (int j = 0; j < cpg; ++j) {
+        const int lc = lc0 + j, vv = lc >> 3, e = lc & 7;
+#pragma unroll
+        for (int w = 0; w < NQ; ++w) a[w] += csum[(w * qstride + e) * VB + vv];
+    }
+#pragma unroll
+    for (int w = 0; w < NQ; ++w) out[w] = a[w];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
                                                      float eps, const float* gamma, const float* beta, int silu, T* y,
@@ -41,17 +91,20 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
     const int ng = div_small(CBLK, inv_cpg), g0 = div_small(cb, inv_cpg);
     const bool on = t < VB * PL && c < C;
     __shared__ float gsum[2 * 64], gmean[64], grstd[64];
-    if (t < 2 * ng) gsum[t] = 0.f;
-    __syncthreads();
+    __shared__ float scratch[16 * (256 + 4)];
+    __shared__ float csum[16 * 8];
     const int64_t base = (int64_t)img * P;
+    float part[16];                       // [0, 8): sums of (x - K), [8, 16): sums of (x - K)^2, per channel of this lane's vector
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part[k] = 0.f;
     if (on) {
-        float s[8] = {}, q[8] = {}, K[8];
+        float K[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) K[e] = gn_pivot(s0, s1, C0, C1, base, div_small(c + e, inv_cpg), cpg);
         auto add = [&](const float8& x) {
             float xv[8] = F8_TO_ARR(x);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; s[e] += dlt; q[e] = fmaf(dlt, dlt, q[e]); }
+            for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; part[e] += dlt; part[8 + e] = fmaf(dlt, dlt, part[8 + e]); }
         };
         int p = lane;
         for (; p + 3 * PL < P; p += 4 * PL) {          // four independent 16-byte loads in flight per lane
@@ -62,13 +115,11 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
             add(x0); add(x1); add(x2); add(x3);
         }
         for (; p < P; p += PL) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int gl = div_small(c + e, inv_cpg) - g0;
-            atomicAdd(&gsum[2 * gl], s[e]);
-            atomicAdd(&gsum[2 * gl + 1], q[e]);
-        }
     }
+    // FIXED summation order (no float atomics: the same input gives the same bits on every box): pixel lanes per channel
+    // through block_colsum, then one thread per group walks its channels in order
+    block_colsum<16, 256>(part, scratch, csum, t, VB, PL);          // csum[(q*8+e)*VB + v]
+    if (t < ng) group_sums<2>(csum, VB, t * cpg, cpg, 8, &gsum[2 * t]);
     __syncthreads();
     if (t < ng && (g0 + t) < G) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
@@ -113,11 +164,16 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(const T* s0, int C0, const 
 
 // backward: dx = rstd*gamma*g - rstd*(s1 + xhat*s2)/cnt with g = dy * act'(xhat*gamma + beta),
 // s1 = sum(g*gamma), s2 = sum(g*gamma*xhat) per (image, group); dgamma += sum g*xhat, dbeta += sum g.
+// Every reduction has a FIXED order.  Inside the workgroup: block_colsum + one thread per group.  Across the images:
+// `part` != nullptr (the fp32 path) -> this workgroup's per-channel sums go to part[img][{dgamma, dbeta}][C] (plain stores)
+// and gn_param_reduce_kernel adds them up image by image behind this launch (it also forms sum_all from sum_img);
+// part == nullptr (bf16 large maps) -> one float atomic per channel per image, as the register-cached kernels do.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
                                                      const float* gamma, const float* beta, int silu, const T* dy,
                                                      const float* stats, T* d0, const T* add0, T* d1, const T* add1, const T* add0b,
-                                                     float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all) {
+                                                     float* dgamma, float* dbeta, float* sum_img, int sum_ld, float* sum_all,
+                                                     float* part) {
     const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
     const float inv_cpg = rcp_small(cpg);
     const int VB = CBLK >> 3, PL = div_small(256, rcp_small(VB));
@@ -126,12 +182,13 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
     const int ng = div_small(CBLK, inv_cpg), g0 = div_small(cb, inv_cpg);
     const bool on = t < VB * PL && c < C;
     __shared__ float gsum[2 * 64];
-    __shared__ float chan[2 * 64];           // per-channel dgamma / dbeta of this workgroup (CBLK <= 64)
-    if (t < 2 * ng) gsum[t] = 0.f;
-    if (t < 2 * CBLK) chan[t] = 0.f;
-    __syncthreads();
+    __shared__ float scratch[32 * (256 + 4)];
+    __shared__ float csum[32 * 8];
     const int64_t base = (int64_t)img * P;
     float ga[8], be[8], mean[8], rstd[8];
+    float acc[32];                        // per channel of this lane's vector: a1, a2, dgamma, dbeta
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
     if (on) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -139,7 +196,6 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
             ga[e] = gamma[c + e]; be[e] = beta[c + e];
             mean[e] = stats[((int64_t)img * G + grp) * 2]; rstd[e] = stats[((int64_t)img * G + grp) * 2 + 1];
         }
-        float a1[8] = {}, a2[8] = {}, dg[8] = {}, db[8] = {};
         auto add = [&](const float8& x, const float8& d) {
             float xv[8] = F8_TO_ARR(x);
             float dv[8] = F8_TO_ARR(d);
@@ -148,9 +204,9 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
                 float xh = (xv[e] - mean[e]) * rstd[e];
                 float gz = dv[e];
                 if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
-                dg[e] = fmaf(gz, xh, dg[e]); db[e] += gz;
+                acc[16 + e] = fmaf(gz, xh, acc[16 + e]); acc[24 + e] += gz;
                 float gg = gz * ga[e];
-                a1[e] += gg; a2[e] = fmaf(gg, xh, a2[e]);
+                acc[e] += gg; acc[8 + e] = fmaf(gg, xh, acc[8 + e]);
             }
         };
         int p = lane;
@@ -162,20 +218,20 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
             add(x0, e0); add(x1, e1);
         }
         for (; p < P; p += PL) add(load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * C + c));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int gl = div_small(c + e, inv_cpg) - g0;
-            atomicAdd(&gsum[2 * gl], a1[e]);
-            atomicAdd(&gsum[2 * gl + 1], a2[e]);
-            atomicAdd(&chan[v * 8 + e], dg[e]);
-            atomicAdd(&chan[CBLK + v * 8 + e], db[e]);
+    }
+    block_colsum<32, 256>(acc, scratch, csum, t, VB, PL);          // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
+    if (t < ng) group_sums<2>(csum, VB, t * cpg, cpg, 8, &gsum[2 * t]);
+    if (t < CBLK && cb + t < C) {            // this workgroup is the only one that holds (image, channel)
+        const float dgv = csum[(16 + (t & 7)) * VB + (t >> 3)], dbv = csum[(24 + (t & 7)) * VB + (t >> 3)];
+        if (part) {
+            part[((int64_t)img * 3) * C + cb + t] = dgv;
+            part[((int64_t)img * 3 + 1) * C + cb + t] = dbv;
+        } else {
+            atomicAdd(&dgamma[cb + t], dgv);
+            atomicAdd(&dbeta[cb + t], dbv);
         }
     }
     __syncthreads();
-    if (t < CBLK && cb + t < C) {            // one global atomic per channel per workgroup (= per image)
-        atomicAdd(&dgamma[cb + t], chan[t]);
-        atomicAdd(&dbeta[cb + t], chan[CBLK + t]);
-    }
     float k1[8], k2[8], ag[8];
     if (on) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
@@ -187,16 +243,11 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
             ag[e] = rstd[e] * ga[e];
         }
     }
-    if (sum_img || sum_all) {               // recycle gsum for the dx column sums once everybody has read it
-        __syncthreads();
-        if (t < 128) gsum[t] = 0.f;
-        __syncthreads();
-    }
+    float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of dx (bias / time-embedding gradient of the producer conv)
     if (on) {
         T* dst; const T* addp; int cc, CS;           // addp: a tensor laid out like dst whose values are added (dst itself = accumulate)
         if (c < C0) { dst = d0; addp = add0; cc = c; CS = C0; } else { dst = d1; addp = add1; cc = c - C0; CS = C1; }
         const T* addq = c < C0 ? add0b : nullptr;    // a second addend for source 0 (accumulate AND a residual-branch gradient)
-        float sx[8] = {};                     // column sums of dx (bias / time-embedding gradient of the producer conv)
         auto put = [&](int p, const float8& x, const float8& d) {
             float xv[8] = F8_TO_ARR(x);
             float dv[8] = F8_TO_ARR(d);
@@ -234,49 +285,32 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const T* s0, int C0, const 
             put(p, x0, e0); put(p + PL, x1, e1);
         }
         for (; p < P; p += PL) put(p, load8(src_ptr(s0, s1, C0, C1, base + p, c)), load8(dy + (base + p) * C + c));
-        if (sum_img || sum_all) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(&gsum[(v * 8 + e)], sx[e]);      // gsum is free again (see barrier below)
-        }
     }
-    if (sum_img || sum_all) {
-        __syncthreads();
+    if (sum_img || sum_all) {               // uniform
+        block_colsum<8, 256>(sx, scratch, csum, t, VB, PL);
         if (t < CBLK && cb + t < C) {
-            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = gsum[t];       // one workgroup owns (image, channel)
-            if (sum_all) atomicAdd(&sum_all[cb + t], gsum[t]);
+            const float r = csum[(t & 7) * VB + (t >> 3)];
+            if (sum_img) sum_img[(int64_t)img * sum_ld + cb + t] = r;              // one workgroup owns (image, channel)
+            if (part) part[((int64_t)img * 3 + 2) * C + cb + t] = r;              // fixed-order mode: the reduce kernel adds the images up
+            else if (sum_all) atomicAdd(&sum_all[cb + t], r);
         }
     }
 }
 
-// Sum over the lanes of a wave that own the same channel vector (lane ids congruent mod VB, VB a power of two):
-// butterfly over the offsets VB, 2VB, ... 32.  Afterwards lanes 0..VB-1 hold the wave's totals, and only those
-// touch LDS -- 64 lanes adding to one LDS address with ds_add_f32 would serialise completely.
-// ---- workgroup column sums through LDS.  Every thread holds K partial values; thread t belongs to column
-// v = t % VB (its 8-channel vector) and the sums run over the 256/VB pixel lanes of each column.
-// (The first version reduced with __shfl_xor: 4 ds_bpermute round trips per value, 128 per thread in the
-// backward -- 20k cycles of a 36k-cycle kernel.)  scratch: K * CS_PITCH floats; out[k * VB + v].
-template <int K, int NT = 256>
-__device__ __forceinline__ void block_colsum(const float (&val)[K], float* scratch, float* out, int t, int VB, int PL) {
-    constexpr int CS_PITCH = NT + 4;
-#pragma unroll
-    for (int k = 0; k < K; ++k) scratch[k * CS_PITCH + t] = val[k];
-    __syncthreads();
-    const int cols = K * VB;                       // <= 256
-    int tpc = 1, tpc_sh = 0;                       // threads per column (power of two)
-    while (tpc * 2 * cols <= NT) { tpc *= 2; ++tpc_sh; }
-    const int col = t >> tpc_sh, part = t - (col << tpc_sh);
-    float sum = 0.f;
-    if (col < cols) {
-        const int k = div_small(col, rcp_small(VB)), v = col - k * VB;
-        // the tpc threads of a column take the pixel lanes INTERLEAVED (l = part, part + tpc, ...): neighbouring lanes then
-        // read neighbouring LDS words.  (Contiguous shares put the threads of a column a multiple of 64 words apart --
-        // 8-way bank conflicts, 62 % of the GroupNorm kernels' LDS cycles by SQ_LDS_BANK_CONFLICT.)
-        const float* src = scratch + k * CS_PITCH + v;
-        for (int l = part; l < PL; l += tpc) sum += src[l * VB];
+// second stage of the fixed-order GroupNorm backward over part[img][{dgamma, dbeta, colsum(dx)}][C]: dgamma[c] += sum_img
+// part[img][0][c], dbeta[c] += sum_img part[img][1][c], sum_all[c] += sum_img part[img][2][c], images in ascending order
+// (one thread per channel)
+__global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* part, int N, int C, float* dgamma, float* dbeta, float* sum_all) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f, s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        a += part[((int64_t)n * 3) * C + c];
+        b += part[((int64_t)n * 3 + 1) * C + c];
+        if (sum_all) s += part[((int64_t)n * 3 + 2) * C + c];
     }
-    for (int o = 1; o < tpc; o <<= 1) sum += __shfl_xor(sum, o, 64);     // <= 3 steps on ONE value
-    if (col < cols && part == 0) out[col] = sum;
-    __syncthreads();
+    dgamma[c] += a; dbeta[c] += b;
+    if (sum_all) sum_all[c] += s;
 }
 
 // ---- register-cached variants (bf16): a lane's share of the slice is at most NP 16-byte vectors per tensor,
@@ -367,10 +401,11 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
     }
     if (MODE != 2) {
         block_colsum<16, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
-        if (t < CBLK && cb + t < C) {
-            const int vv = t >> 3, e = t & 7, gl = div_small(cb + t, inv_cpg) - g0;
-            atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
-            atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
+        // one thread per group walks its channels in order (it was an LDS float atomic per channel: arrival order)
+        if (t < ng) {
+            float gv[2];
+            group_sums<2>(csum, VB, t * cpg, cpg, 8, gv);
+            gsum[2 * t] += gv[0]; gsum[2 * t + 1] += gv[1];
         }
     }
     __syncthreads();
@@ -516,12 +551,16 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
     }
     if (MODE != 2) {
         block_colsum<32, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
-        if (t < CBLK && cb + t < C) {
-            const int vv = t >> 3, e = t & 7, gl = div_small(cb + t, inv_cpg) - g0;
-            atomicAdd(&gsum[2 * gl], csum[e * VB + vv]);
-            atomicAdd(&gsum[2 * gl + 1], csum[(8 + e) * VB + vv]);
+        if (t < CBLK && cb + t < C) {            // across images: one float atomic per (image, channel) (bf16 path)
+            const int vv = t >> 3, e = t & 7;
             atomicAdd(&dgamma[cb + t], csum[(16 + e) * VB + vv]);
             atomicAdd(&dbeta[cb + t], csum[(24 + e) * VB + vv]);
+        }
+        if (t >= 64 && t < 64 + ng) {            // inside the workgroup: fixed order (a second wave, next to the atomics above)
+            const int gi = t - 64;
+            float gv[2];
+            group_sums<2>(csum, VB, gi * cpg, cpg, 8, gv);
+            gsum[2 * gi] += gv[0]; gsum[2 * gi + 1] += gv[1];
         }
     }
     MDM_T(const unsigned long long ts2 = nstamp_now();)
@@ -633,36 +672,47 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* Pm, T* dP, in
     for (int j = lane; j < L; j += 64) Elem<T>::st(g + j, Elem<T>::ld(p + j) * (Elem<T>::ld(g + j) - dot));
 }
 
-// ---- column sums of dY[N][P][C]
+// ---- column sums of dY[N][P][C]: per_img[n][c] (=|+=) sum_p dY[n][p][c], dbias[c] += sum_n sum_p dY[n][p][c].
+// A workgroup owns 64 channels (8 vectors x 32 pixel lanes) of `imgs` consecutive images and walks them in order, so that
+// with imgs = N (the fp32 path) dbias has ONE writer per channel and a fixed summation order; with imgs = 1 (bf16: more
+// workgroups) the images meet through one float atomic per channel per image.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* dY, int P, int C, float* per_img, int ld, int acc_img, float* dbias) {
-    // grid (C/8 vector groups of 32.., N): thread t -> vector v = blockIdx.x*32 + t%32? keep it simple:
-    // each workgroup owns one image and 8 vectors (64 channels); 32 pixel lanes per vector.
+__global__ __launch_bounds__(256) void colsum_kernel(const T* dY, int P, int C, float* per_img, int ld, int acc_img, float* dbias,
+                                                     int imgs, int N) {
     __shared__ float red[32][65];
-    const int img = blockIdx.y, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int v = blockIdx.x * 8 + (t & 7), lanep = t >> 3;      // 8 vectors x 32 pixel lanes
-    float s[8] = {};
-    if (v * 8 < C) {
-        for (int p = lanep; p < P; p += 32) {
-            float8 x = load8(dY + ((int64_t)img * P + p) * C + v * 8);
-            s[0] += x.lo.x; s[1] += x.lo.y; s[2] += x.lo.z; s[3] += x.lo.w;
-            s[4] += x.hi.x; s[5] += x.hi.y; s[6] += x.hi.z; s[7] += x.hi.w;
+    float total = 0.f;
+    for (int img = blockIdx.y * imgs; img < min(N, (int)(blockIdx.y + 1) * imgs); ++img) {
+        float s[8] = {};
+        if (v * 8 < C) {
+            for (int p = lanep; p < P; p += 32) {
+                float8 x = load8(dY + ((int64_t)img * P + p) * C + v * 8);
+                s[0] += x.lo.x; s[1] += x.lo.y; s[2] += x.lo.z; s[3] += x.lo.w;
+                s[4] += x.hi.x; s[5] += x.hi.y; s[6] += x.hi.z; s[7] += x.hi.w;
+            }
         }
-    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[lanep][(t & 7) * 8 + e] = s[e];
-    __syncthreads();
-    if (t < 64) {
-        float a = 0.f;
+        for (int e = 0; e < 8; ++e) red[lanep][(t & 7) * 8 + e] = s[e];
+        __syncthreads();
+        if (t < 64) {
+            float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) a += red[r][t];
-        int c = blockIdx.x * 64 + t;
-        if (c < C) {
-            if (per_img) {
+            for (int r = 0; r < 32; ++r) a += red[r][t];
+            const int c = blockIdx.x * 64 + t;
+            if (c < C && per_img) {
                 float* q = per_img + (int64_t)img * ld + c;
                 *q = acc_img ? *q + a : a;
             }
-            if (dbias) atomicAdd(&dbias[c], a);
+            total += a;
+        }
+        __syncthreads();
+    }
+    if (t < 64) {
+        const int c = blockIdx.x * 64 + t;
+        if (c < C && dbias) {
+            if (imgs >= N) dbias[c] += total;            // single writer
+            else atomicAdd(&dbias[c], total);
         }
     }
 }
@@ -846,9 +896,14 @@ extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const 
 #undef GN_BWD_REG
         return launch_status("groupnorm_bwd");
     }
+    // fp32 path: fixed summation order across the images too (per-image partials in ws + a second stage); bf16 large maps: atomics
+    float* part = dtype == MDM_F32 ? ws : nullptr;
+    MDM_REQUIRE(dtype != MDM_F32 || ws, "groupnorm_bwd: the fp32 path needs ws (>= 3 * N * C floats) for its fixed-order sums");
     DISPATCH_T(dtype, hipLaunchKernelGGL((gn_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)src0, C0,
                                          (const T*)src1, C1, P, G, cblk, gamma, beta, silu, (const T*)dy, stats, (T*)dst0,
-                                         (const T*)add0, (T*)dst1, (const T*)add1, (const T*)add0b, dgamma, dbeta, sum_img, sum_ld, sum_all));
+                                         (const T*)add0, (T*)dst1, (const T*)add1, (const T*)add0b, dgamma, dbeta, sum_img, sum_ld, sum_all, part));
+    if (part)
+        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, N, C, dgamma, dbeta, sum_all);
     return launch_status("groupnorm_bwd");
 }
 
@@ -914,8 +969,9 @@ extern "C" int mdm_silu_bwd(const float* x, const float* dy, float* dx, int acc,
 extern "C" int mdm_colsum(int dtype, const void* dY, int N, int P, int C, float* per_img, int ld, int acc_img, float* dbias,
                           void* stream) {
     MDM_REQUIRE(C % 8 == 0 && N > 0 && P > 0, "colsum: bad shape");
-    dim3 grid(cdiv(C, 64), N);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, pick_stream(stream), (const T*)dY, P, C, per_img, ld, acc_img, dbias));
+    const int imgs = dtype == MDM_F32 ? N : 1;          // fp32 path: fixed summation order over the images (see colsum_kernel)
+    dim3 grid(cdiv(C, 64), cdiv(N, imgs));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, pick_stream(stream), (const T*)dY, P, C, per_img, ld, acc_img, dbias, imgs, N));
     return launch_status("colsum");
 }
 

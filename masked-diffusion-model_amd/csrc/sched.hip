@@ -17,8 +17,8 @@ __device__ __forceinline__ uint4 philox_at(const uint64_t* rng, int stream_id, u
 
 __global__ void draw_timesteps_kernel(const uint64_t* rng, const int32_t* used, int n_used, const double* table,
                                       const float* wtab, int N, float* t_out, double* amount_out, float* weight_out,
-                                      int32_t* idx_out, const double* table2, double* out2, float* zero_out) {
-    if (zero_out && blockIdx.x == 0 && threadIdx.x == 0) *zero_out = 0.f;      // the step's loss accumulator (mdm_loss_fwd_bwd adds)
+                                      int32_t* idx_out, const double* table2, double* out2, long long* zero_out) {
+    if (zero_out && blockIdx.x == 0 && threadIdx.x == 0) { zero_out[0] = 0; zero_out[1] = 0; }   // the step's loss accumulator (mdm_loss_fwd_bwd adds)
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     uint4 r = philox_at(rng, 0, (uint64_t)n);
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void degrade_kernel(const float* x0, const flo
                                                       float* x_t, float* mask, float* mean_pixel, int keep_lds) {
     const int img = blockIdx.x, t = threadIdx.x;
     const double thr = amount ? amount[(int64_t)img * amount_stride] : 0.0;
-    __shared__ float s_sum[8], s_cnt[8], s_fill[8];
+    __shared__ float s_sum[8], s_cnt[8], s_fill[8], s_wsum[4][8], s_wcnt[4][8];
     // The keep flags of the image, drawn ONCE into LDS (keep_lds != 0: Cm * HW bytes fit and HW % 4 == 0): one Philox call
     // yields the uniforms of 4 consecutive elements, and both passes and all C channels of a 1-channel mask read the same flag
     // (computing it at every use cost 24 Philox calls per thread at cfg2).  Same uniforms, same fp64 comparison.
@@ -84,7 +84,12 @@ __global__ __launch_bounds__(256) void degrade_kernel(const float* x0, const flo
                 else { a += xv * (1.f - k); n += 1.f - k; }
             }
             a = wave_sum(a); n = wave_sum(n);
-            if ((t & 63) == 0) { atomicAdd(&s_sum[c], a); atomicAdd(&s_cnt[c], n); }
+            if ((t & 63) == 0) { s_wsum[t >> 6][c] = a; s_wcnt[t >> 6][c] = n; }      // per-wave slots, summed in wave order below
+        }
+        __syncthreads();
+        if (t < C) {
+            s_sum[t] = (s_wsum[0][t] + s_wsum[1][t]) + (s_wsum[2][t] + s_wsum[3][t]);
+            s_cnt[t] = (s_wcnt[0][t] + s_wcnt[1][t]) + (s_wcnt[2][t] + s_wcnt[3][t]);
         }
         __syncthreads();
         if (t == 0) {
@@ -192,7 +197,7 @@ __global__ void zero_pad_channels_kernel(T* x_nhwc, int C, int Cp, int64_t npix)
 template <typename T>
 __global__ __launch_bounds__(256) void loss_kernel(const T* pred, const float* x_in, const float* s, const float* x0,
                                                    const float* w, int N, int C, int HW, int Cp, float gscale, T* dpred,
-                                                   float* loss_accum) {
+                                                   unsigned long long* loss_q40) {
     const int64_t npix = (int64_t)N * HW;
     const float inv_numel = 1.f / ((float)N * (float)C * (float)HW);
     float local = 0.f;
@@ -232,7 +237,14 @@ __global__ __launch_bounds__(256) void loss_kernel(const T* pred, const float* x
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_accum, (part[0] + part[1] + part[2] + part[3]) * inv_numel);
+    // The workgroups meet in a FIXED-POINT accumulator (Q23.40, two's complement): integer adds commute, so the sum does not
+    // depend on the order the workgroups finish in (a float atomic does: the fp32 loss was not reproducible run to run).
+    // 2^-40 resolves every partial >= 2^-16 exactly; a partial that is not finite or >= 2^22 bumps the flag word instead.
+    if (threadIdx.x == 0) {
+        const float v = ((part[0] + part[1]) + (part[2] + part[3])) * inv_numel;
+        if (fabsf(v) < 4194304.f) atomicAdd(loss_q40, (unsigned long long)__float2ll_rn(v * 1099511627776.f));
+        else atomicAdd(loss_q40 + 1, 1ull);
+    }
 }
 
 template <typename T>
@@ -294,10 +306,10 @@ using namespace mdm;
 
 extern "C" int mdm_draw_timesteps(const uint64_t* rng, const int32_t* used, int n_used, const double* table, const float* wtab,
                                   int N, float* t_out, double* amount_out, float* weight_out, int32_t* idx_out, const double* table2,
-                                  double* out2, float* zero_out, void* stream) {
+                                  double* out2, int64_t* zero_out, void* stream) {
     MDM_REQUIRE(rng && used && table && n_used > 0 && N > 0 && (!out2 || table2), "draw_timesteps: bad arguments");
     hipLaunchKernelGGL(draw_timesteps_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rng, used, n_used, table,
-                       wtab, N, t_out, amount_out, weight_out, idx_out, table2, out2, zero_out);
+                       wtab, N, t_out, amount_out, weight_out, idx_out, table2, out2, reinterpret_cast<long long*>(zero_out));
     return launch_status("draw_timesteps");
 }
 
@@ -343,9 +355,22 @@ extern "C" int mdm_shift(const float* x_t, const float* z, const double* ratio, 
     return launch_status("shift");
 }
 
+extern "C" int mdm_zero_pad_channels(int dtype, void* x_nhwc, int64_t npix, int C, int Cp, void* stream) {
+    MDM_REQUIRE(x_nhwc && npix > 0 && C > 0 && Cp >= C && Cp % 8 == 0, "zero_pad_channels: bad arguments");
+    MDM_REQUIRE(dtype == MDM_F32 || dtype == MDM_BF16, "zero_pad_channels: bad dtype %d", dtype);
+    if (Cp == C) return 0;
+    const int64_t n = npix * (Cp - C);
+    if (dtype == MDM_BF16)
+        hipLaunchKernelGGL((zero_pad_channels_kernel<bf16_t>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x_nhwc, C, Cp, npix);
+    else
+        hipLaunchKernelGGL((zero_pad_channels_kernel<float>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (float*)x_nhwc, C, Cp, npix);
+    return launch_status("zero_pad_channels");
+}
+
 extern "C" int mdm_loss_fwd_bwd(int dtype, const void* pred, const float* x_in, const float* s, const float* x0, const float* w,
-                                int N, int C, int H, int W, int Cp, float gscale, void* dpred, float* loss_accum, void* stream) {
-    MDM_REQUIRE(pred && x_in && x0 && loss_accum && Cp >= C && Cp % 8 == 0, "loss: bad arguments (Cp must be a multiple of 8)");
+                                int N, int C, int H, int W, int Cp, float gscale, void* dpred, int64_t* loss_q40, void* stream) {
+    MDM_REQUIRE(pred && x_in && x0 && loss_q40 && Cp >= C && Cp % 8 == 0, "loss: bad arguments (Cp must be a multiple of 8)");
+    unsigned long long* loss_accum = reinterpret_cast<unsigned long long*>(loss_q40);
     int grid = sgrid((int64_t)N * H * W);
     if (grid > 256) grid = 256;            // one same-address atomic per workgroup at the end: keep them few
     if (dtype == MDM_BF16)

@@ -79,6 +79,7 @@ _PROTOS = {
     "mdm_degrade": ([vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp], i32),
     "mdm_index_mask": ([vp, i32, vp, i32, i32, i32, i32, vp, vp], i32),
     "mdm_shift": ([vp, vp, vp, vp, i32, i32, f32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp], i32),
+    "mdm_zero_pad_channels": ([i32, vp, i64, i32, i32, vp], i32),
     "mdm_loss_fwd_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp], i32),
     "mdm_sampler_x0": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp], i32),
     "mdm_sampler_update": ([vp, vp, vp, vp, i32, i64, vp], i32),

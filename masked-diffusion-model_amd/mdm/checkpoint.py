@@ -13,8 +13,13 @@ hooks of main_train_masked.py:195-225, and resumes with `accelerator.load_state(
     <path>/optimizer.bin                             torch.save(optimizer.state_dict()): torch.optim.AdamW layout,
                                                      parameters indexed in `model.parameters()` order
     <path>/scheduler.bin                             torch.save(lr_scheduler.state_dict())
-    <path>/random_states_<rank>.pkl                  RNG states (here also the device Philox key/offset)
+    <path>/random_states_<rank>.pkl                  torch.save (despite the suffix) of {step, random_state,
+                                                     numpy_random_seed, torch_manual_seed[, torch_cuda_manual_seed]}
+                                                     (here also the device Philox key/offset under its own key)
 
+optimizer.bin / scheduler.bin / random_states_<rank>.pkl are PINNED: tests/golden/train_traj.npz holds the key / shape /
+dtype manifest of the directory a real `accelerate.Accelerator.save_state` wrote at the end of the reference's `train()`
+run (make_golden.gen_train_traj), and tests/test_device_path_gpu.py compares what is written here against it.
 `diffusers` is absent offline, so the two config.json files follow its published layout from the
 call-site arguments -- parity unpinned, like the EMA decay schedule.  The tensors use the reference's 304-key
 grammar and OIHW / [out,in] shapes, so `unet/` can be loaded into the reference's unet6 with
@@ -75,7 +80,7 @@ def load_model_tensors(folder):
     return cfg, _load_tensors(folder)
 
 
-def save_state(path, model, optimizer=None, ema=None, lr_scheduler=None, scheduler=None, rank=0, main=True, extra=None):
+def save_state(path, model, optimizer=None, ema=None, lr_scheduler=None, scheduler=None, rank=0, main=True, extra=None, step=0):
     os.makedirs(path, exist_ok=True)
     if main:
         save_model(model, os.path.join(path, "unet"))
@@ -85,13 +90,16 @@ def save_state(path, model, optimizer=None, ema=None, lr_scheduler=None, schedul
             torch.save(optimizer.state_dict(), os.path.join(path, "optimizer.bin"))
         if lr_scheduler is not None:
             torch.save(lr_scheduler.state_dict(), os.path.join(path, "scheduler.bin"))
-    states = dict(random_state=random.getstate(), numpy_random_seed=np.random.get_state(), torch_manual_seed=torch.get_rng_state())
+    # accelerate.checkpointing.save_accelerator_state: one torch.save'd dict per rank
+    states = dict(step=int(step), random_state=random.getstate(), numpy_random_seed=np.random.get_state(),
+                  torch_manual_seed=torch.get_rng_state())
+    if torch.cuda.is_available():
+        states["torch_cuda_manual_seed"] = torch.cuda.get_rng_state_all()
     if scheduler is not None and getattr(scheduler, "dev_rng", None) is not None:
         states["mdm_philox"] = [int(v) for v in scheduler.dev_rng.dev.cpu().tolist()]
     if extra:
         states["mdm_extra"] = dict(extra)
-    with open(os.path.join(path, f"random_states_{rank}.pkl"), "wb") as fh:
-        pickle.dump(states, fh)
+    torch.save(states, os.path.join(path, f"random_states_{rank}.pkl"))
 
 
 def load_state(path, model, optimizer=None, ema=None, lr_scheduler=None, scheduler=None, rank=0):
@@ -108,12 +116,20 @@ def load_state(path, model, optimizer=None, ema=None, lr_scheduler=None, schedul
     p = os.path.join(path, f"random_states_{rank}.pkl")
     extra = {}
     if os.path.exists(p):
-        with open(p, "rb") as fh:
-            st = pickle.load(fh)
+        try:
+            st = torch.load(p, map_location="cpu", weights_only=False)
+        except Exception:               # round-2 checkpoints: a plain pickle
+            with open(p, "rb") as fh:
+                st = pickle.load(fh)
         random.setstate(st["random_state"])
         np.random.set_state(st["numpy_random_seed"])
         torch.set_rng_state(st["torch_manual_seed"])
+        if "torch_cuda_manual_seed" in st and torch.cuda.is_available() and len(st["torch_cuda_manual_seed"]) == torch.cuda.device_count():
+            torch.cuda.set_rng_state_all(st["torch_cuda_manual_seed"])
+        extra_step = st.get("step")
         if scheduler is not None and "mdm_philox" in st:
             scheduler.dev_rng.dev.copy_(torch.tensor(st["mdm_philox"], dtype=torch.int64))
-        extra = st.get("mdm_extra", {})
+        extra = dict(st.get("mdm_extra", {}))
+        if extra_step is not None:
+            extra.setdefault("step", int(extra_step))
     return extra

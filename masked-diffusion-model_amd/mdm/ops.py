@@ -175,10 +175,12 @@ def wgrad_group_split(g: ConvGeom, slabs_per_item=48):
 
 
 def matmul(dt, layout, M, N, K, A, lda, B, ldb, D, ldd, batch=1, sA=0, sB=0, sD=0, alpha=1.0, bias=None,
-           acc=0, out_f32=0, splitk=1, dbias=None):
-    """Plain (batched) contraction in one of the three layouts (see mdm_hip.h).  dbias (layout 2): += column sums of A."""
+           acc=0, out_f32=0, splitk=1, dbias=None, ws=None):
+    """Plain (batched) contraction in one of the three layouts (see mdm_hip.h).  dbias (layout 2): += column sums of A.
+    splitk > 1 needs `ws` (fp32 tensor, >= splitk * M * N elements): without a workspace the reduction is not split."""
     _lib.gemm(dtype=dt, layout=layout, M=M, N=N, K=K, batch=batch, sA=sA, sB=sB, sD=sD, A=A, lda=lda, B=B, ldb=ldb,
-              D0=D, ldd0=ldd, N0=N, alpha=alpha, bias=bias, acc0=acc, out_f32=out_f32, splitk=splitk, dbias=dbias)
+              D0=D, ldd0=ldd, N0=N, alpha=alpha, bias=bias, acc0=acc, out_f32=out_f32, splitk=splitk, dbias=dbias,
+              ws=ws, ws_bytes=(ws.numel() * 4 if ws is not None else 0))
 
 
 def skinny_supported(M, N, K, splits=1):

@@ -84,7 +84,7 @@ class AdamW:
         state = {i: dict(step=torch.tensor(float(self.t)), exp_avg=m[k], exp_avg_sq=v[k]) for i, k in enumerate(order)} if self.t else {}
         g = self.param_groups[0]
         group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=False,
-                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=True,
                      initial_lr=g["initial_lr"], params=list(range(len(order))))
         return dict(state=state, param_groups=[group])
 
@@ -176,7 +176,8 @@ class LambdaLR:
         return [self.opt.param_groups[0]["lr"]]
 
     def state_dict(self):          # torch.optim.lr_scheduler.LambdaLR.state_dict() fields (the lambda itself is not saved)
-        return dict(base_lrs=[self.base], last_epoch=self.k, _step_count=self.k + 1, _last_lr=self.get_last_lr(), lr_lambdas=[None])
+        return dict(base_lrs=[self.base], last_epoch=self.k, _step_count=self.k + 1, _is_initial=False, _get_lr_called_within_step=False,
+                    _last_lr=self.get_last_lr(), lr_lambdas=[None])
 
     def load_state_dict(self, sd):
         self.k = int(sd["last_epoch"])
@@ -218,14 +219,19 @@ class Accelerator:
     """The subset of `accelerate.Accelerator` the trainers touch, backed by
     torch.distributed (RCCL on ROCm) when a process group is initialised."""
 
-    def __init__(self, gradient_accumulation_steps=1, mixed_precision="bf16", device=None):
+    def __init__(self, gradient_accumulation_steps=1, mixed_precision="bf16", device=None, split_batches=False):
         import torch.distributed as dist
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.num_processes = self.dist.get_world_size() if self.dist else 1
         self.process_index = self.dist.get_rank() if self.dist else 0
         self.mixed_precision = mixed_precision
-        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+        if self.gradient_accumulation_steps < 1:
+            raise ValueError(f"gradient_accumulation_steps={gradient_accumulation_steps}")
+        self.split_batches = split_batches       # accelerate default False: the LR schedule then steps num_processes times per update
         self.sync_gradients = True
+        self.end_of_dataloader = False           # set by the trainer's batch loop (accelerate: by its prepared dataloader)
+        self.step = 0
         self.device = torch.device(device) if device is not None else (
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         self._ckpt = {}
@@ -249,9 +255,22 @@ class Accelerator:
                 self._ckpt["ema"] = o
         return objs if len(objs) != 1 else objs[0]
 
-    def accumulate(self, model):
+    def accumulate(self, model=None):
+        """`with accelerator.accumulate(model):` (ms:139) -- accelerate's `_do_sync`: the micro-step counter decides
+        `sync_gradients`; the last batch of the dataloader always syncs and restarts the count.  What upstream hangs on the
+        flag (scaled backward, clip, optimizer / LR step, EMA) is done by TrainStep / Trainer._step."""
         import contextlib
-        return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.end_of_dataloader:
+                self.step = 0
+                self.sync_gradients = True
+            else:
+                self.step += 1
+                self.sync_gradients = (self.step % self.gradient_accumulation_steps) == 0
+            yield
+        return ctx()
 
     def backward(self, loss):       # the fused train step has already produced the gradients
         return None
@@ -283,7 +302,7 @@ class Accelerator:
         if c.get("model") is None:
             raise RuntimeError("Accelerator.save_state: no model registered (prepare() / register_for_checkpointing())")
         checkpoint.save_state(output_dir, c["model"], c.get("optimizer"), c.get("ema"), c.get("lr_scheduler"), c.get("scheduler"),
-                              rank=self.process_index, main=self.is_main_process, extra=extra or None)
+                              rank=self.process_index, main=self.is_main_process, extra=extra or None, step=self.step)
         self.wait_for_everyone()
         return output_dir
 
@@ -293,5 +312,7 @@ class Accelerator:
         c = self._ckpt
         if c.get("model") is None:
             raise RuntimeError("Accelerator.load_state: no model registered (prepare() / register_for_checkpointing())")
-        return checkpoint.load_state(input_dir, c["model"], c.get("optimizer"), c.get("ema"), c.get("lr_scheduler"), c.get("scheduler"),
-                                     rank=self.process_index)
+        extra = checkpoint.load_state(input_dir, c["model"], c.get("optimizer"), c.get("ema"), c.get("lr_scheduler"), c.get("scheduler"),
+                                      rank=self.process_index)
+        self.step = int(extra.get("step", self.step))          # accelerate restores its micro-step counter too
+        return extra

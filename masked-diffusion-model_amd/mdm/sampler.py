@@ -2,8 +2,9 @@
 
 Mirrors reference code/sampler.py: `_get_latent_initial` (:46-83), `sample` (:102-106) and
 `_sample_mean_shift_momentum` (:109-261) for the options that run upstream at HEAD
-(`sampling_mask_dependency` in {independent, dependent_prev}, `momentum_adaptive` in
-{base_sampling, base_momentum}).
+(`sampling_mask_dependency` in {independent, dependent_prev, dependent_t -- the last for
+'thresholding' with mean_option 'degraded_area' or "0", scheduler.py:480-549}, `momentum_adaptive`
+in {base_sampling, base_momentum}).
 
 What is different from the reference loop (same arithmetic, same RNG order in replay mode):
   * the whole state stays on the GPU; nothing is copied to the host inside the loop.  The
@@ -49,6 +50,11 @@ def gather_shards(local, n, group=None):
 class Sampler:
     def __init__(self, dataset, args, Scheduler, dataset_hist):
         self.dataset, self.args, self.Scheduler, self.dataset_hist = dataset, args, Scheduler, dataset_hist
+        # Optional observer `f(i, slot, x_t)` called at the top of every reverse step of the host-driven loop; it may
+        # overwrite x_t in place.  The parity tests use it for TEACHER FORCING (x_t <- the oracle's x_t of that step): an
+        # untrained U-Net iterated 1000 times is a chaotic map -- the reference's own fp32 run is O(1) away from its fp64
+        # run by then -- so a long free-running comparison measures conditioning; the per-step one measures the kernels.
+        self.step_hook = None
 
     # ---- multi-GPU: `sample_num` is partitioned over the ranks of the default process group ----------------
     def _shard(self):
@@ -64,7 +70,9 @@ class Sampler:
         return hi - lo
 
     def _get_latent_initial(self, model=None):
-        """Constant-colour start image per sample, drawn on the host like sampler.py:46-83."""
+        """Constant-colour start image per sample, drawn on the host like sampler.py:46-83.  Sharded sampling: drawn for the
+        FULL sample_num on every rank (all ranks are seeded alike, main_train_masked.py:441-445) and sliced to this rank's rows
+        by the caller -- a rank drawing only its own share would start from the same colours as every other rank."""
         a = self.args
         if a.mean_area == "image-wise":
             d = 1
@@ -102,14 +110,18 @@ class Sampler:
         import argparse
         full = self.args
         n = full.sample_num
+        lo, hi = shard_bounds(n, rank, world)
         try:
-            self.args = argparse.Namespace(**vars(full))
-            self.args.sample_num = self.local_sample_num()
-            if self.args.sample_num == 0:
+            if hi == lo:
                 raise ValueError(f"sample_num={n} < world size {world}: a rank would sample nothing")
-            x0, hist = self._sample_mean_shift_momentum(model, timesteps_used_epoch)
+            latent = self._get_latent_initial(model)[lo:hi]           # the full draw, this rank's rows
+            self.args = argparse.Namespace(**vars(full))
+            self.args.sample_num = hi - lo
+            self.Scheduler.replay_rows = (lo, hi, n)                  # every later host draw: full batch, sliced (replay mode)
+            x0, hist = self._sample_mean_shift_momentum(model, timesteps_used_epoch, latent=latent)
         finally:
             self.args = full
+            self.Scheduler.replay_rows = None
         def gather_hist(h):             # [T+1, n_local, C, H, W], on the host when args.sample_history is True
             g = gather_shards(h.to(x0.device).transpose(0, 1).contiguous(), n).transpose(0, 1)
             return g if h.is_cuda else g.cpu()
@@ -183,6 +195,9 @@ class Sampler:
             if dep == "independent":
                 degrade(amt_t, 3, None, d_t, m_t, mi_t)
                 degrade(amt_next, 4, None, d_next, m_next, mi_next)
+            elif dep == "dependent_t":                    # nested masks: the SAME Philox stream thresholded at both ratios
+                degrade(amt_t, 3, None, d_t, m_t, mi_t)
+                degrade(amt_next, 3, None, d_next, m_next, mi_next)
             else:
                 degrade(None, 0, m_next, d_t, None, None)
                 degrade(amt_next, 4, None, d_next, m_next, mi_next)
@@ -201,27 +216,31 @@ class Sampler:
         self._graph_keep = (keep, gb, gl)
         return x0_hat
 
-    def _sample_mean_shift_momentum(self, model, timesteps):
+    def _sample_mean_shift_momentum(self, model, timesteps, latent=None):
         from .unet import UNet
         a, S = self.args, self.Scheduler
         dev = S.device
         T = len(timesteps)
         n, c, hw = a.sample_num, a.out_channel, a.data_size
         dep, mode = a.sampling_mask_dependency, a.momentum_adaptive
-        if dep not in ("independent", "dependent_prev"):
-            raise UnboundLocalError(f"sampling_mask_dependency={dep!r} does not run upstream (D5)")
+        if dep not in ("independent", "dependent_prev", "dependent_t"):
+            raise UnboundLocalError(f"sampling_mask_dependency={dep!r} is not an option upstream")
+        if dep == "dependent_t":                # runs upstream for a sub-case only (scheduler.py:480-549); same errors here
+            S._check_dependent_args(a, a.mean_option, a.mean_area)
+            S._check_degrade_args(torch.empty(1, c, 1, 1))
         if mode not in ("base_sampling", "base_momentum"):
             raise UnboundLocalError(f"momentum_adaptive={mode!r} does not run upstream (D4)")
         hist_mode = getattr(a, "sample_history", True)
         fused = isinstance(model, UNet)
         if fused:
             assert (model.N, model.H, model.W) == (n, hw, hw), "UNet plan was built for another batch/extent"
-        x_t = self._get_latent_initial(model).to(dev, torch.float32).contiguous()
+        x_t = (latent if latent is not None else self._get_latent_initial(model)).to(dev, torch.float32).contiguous()
         m_next = torch.zeros(n, c, hw, hw, device=dev)
         hist = None
         if hist_mode:
             hist = {k: torch.zeros(T + 1, n, c, hw, hw, device=dev) for k in HISTORY_NAMES}
-        if fused and not hist_mode and S.rng_mode == "device" and model.use_graph and getattr(a, "sampler_graph", True):
+        if (fused and not hist_mode and S.rng_mode == "device" and model.use_graph and getattr(a, "sampler_graph", True)
+                and self.step_hook is None):
             return self._sample_graph(model, timesteps, x_t, dep, mode), []
         x0_hat = torch.empty_like(x_t)
         pred_nchw = torch.empty_like(x_t) if hist_mode else None
@@ -232,6 +251,8 @@ class Sampler:
             slot = T - i
             S.dev_rng.advance()
             time = torch.full((n,), float(timesteps[i]), device=dev)
+            if self.step_hook is not None:
+                self.step_hook(i, slot, x_t)
             if hist_mode:
                 hist["sample_t"][slot].copy_(x_t)
             nhwc = (model.dt, model.x_in.data, model.cin_p) if fused else None
@@ -245,6 +266,8 @@ class Sampler:
             if dep == "independent":                                                 # :175-181
                 d_t, m_t, _ = S.degrade_independent_base_sampling(n_t, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area, _stream=3)
                 d_next, m_next, _ = S.degrade_independent_base_sampling(n_next, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area, _stream=4)
+            elif dep == "dependent_t":                                               # :191-196
+                d_t, m_t, _, d_next, m_next, _ = S.degrade_dependent_base_sampling(n_t, n_next, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area)
             else:                                                                    # :184-188
                 m_t = None
                 d_t = S.degrade_with_mask(x0_hat, m_next, mean_option=a.mean_option, mean_area=a.mean_area)
@@ -252,7 +275,7 @@ class Sampler:
             if hist_mode:
                 hist["shift"][slot].copy_(s); hist["shifted"][slot].copy_(x_in); hist["mask"][slot].copy_(pred_nchw)
                 hist["shifted_result"][slot].copy_(shifted0); hist["sample_0"][slot].copy_(x0_hat)
-                if dep == "independent":
+                if dep in ("independent", "dependent_t"):
                     hist["degraded_mask"][slot].copy_(m_t); hist["degraded_mask_next"][slot].copy_(m_next)
                 else:
                     hist["degraded_mask"][slot].copy_(m_next)

@@ -82,6 +82,20 @@ class Scheduler:
             import torch.distributed as dist
             rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         self.dev_rng = DeviceRng(self.device, getattr(args, "seed", 0), rank)
+        # Sharded sampling (mdm.Sampler over a process group): (lo, hi, n) = this rank computes rows [lo, hi) of an n-sample
+        # batch.  The reference seeds every rank alike (main_train_masked.py:441-445), so a rank that drew only ITS rows from the
+        # host generator would draw the same numbers as every other rank -- W copies of the same samples.  Host draws are
+        # therefore made for all n samples on every rank (same seed -> same numbers) and sliced: the gathered batch equals
+        # what one process computes.
+        self.replay_rows = None
+
+    def _host_rows(self, n_local):
+        """(n to draw on the host, slice of it that is ours)."""
+        if self.replay_rows is None:
+            return n_local, slice(None)
+        lo, hi, n = self.replay_rows
+        assert hi - lo == n_local, (self.replay_rows, n_local)
+        return n, slice(lo, hi)
 
     # ---- schedule tables (host, once per run) -------------------------------------
     def update_ddpm_num_steps(self, max_time=None):
@@ -174,8 +188,9 @@ class Scheduler:
             return 1
         raise UnboundLocalError("select_degrade_pixel")
 
-    def _degrade(self, amount, img, mean_option, mean_area, rng_stream, mask_in=None, want_mask=True):
-        """Core of the three degrade_* methods -> (x_t, mask, mean_pixel[N,C])."""
+    def _degrade(self, amount, img, mean_option, mean_area, rng_stream, mask_in=None, want_mask=True, u=None, u_out=None):
+        """Core of the degrade_* methods -> (x_t, mask, mean_pixel[N,C]).  `u`: uniforms already on the device to threshold
+        (replay mode, thresholding) instead of drawing; `u_out`: a list that receives the uniforms this call drew."""
         img = img.to(self.device, torch.float32).contiguous()
         N, C, H, W = img.shape
         HW = H * W
@@ -183,7 +198,6 @@ class Scheduler:
         x_t = torch.empty_like(img)
         mask = torch.empty_like(img) if want_mask else None
         mp = torch.empty(N, C, device=self.device)
-        u = None
         amt = None
         Cm = 1
         if mask_in is None:
@@ -193,18 +207,25 @@ class Scheduler:
                 if amount.dtype.is_floating_point:
                     raise TypeError("indexing needs integer pixel counts (linear/exponential schedules give ratios, D7)")
                 if self.rng_mode == "replay":       # N serial CPU randperms, like scheduler.py:281-282
-                    m = torch.ones(N, HW)
-                    for i, num in enumerate(amount.cpu()):
+                    nh, rows = self._host_rows(N)
+                    counts = amount.cpu()
+                    if nh != N:                     # sharded sampler: every sample of a step has the same count
+                        counts = counts[:1].expand(nh)
+                    m = torch.ones(nh, HW)
+                    for i, num in enumerate(counts):
                         m[i, torch.randperm(HW)[:num]] = 0.0
-                    mask_in = m.reshape(N, 1, H, W).expand(N, C, H, W).contiguous().to(self.device)
+                    mask_in = m[rows].reshape(N, 1, H, W).expand(N, C, H, W).contiguous().to(self.device)
                 else:
                     mask_in = torch.empty_like(img)
                     cnt = amount.to(self.device, torch.float64).contiguous()
                     call("mdm_index_mask", ptr(cnt), 1, ptr(self.dev_rng.dev), rng_stream, N, C, HW, ptr(mask_in), stream())
             else:
                 amt = amount.to(self.device, torch.float64).contiguous()
-                if self.rng_mode == "replay":
-                    u = torch.empty(N, Cm * HW, dtype=torch.float32).uniform_(0.0, 1.0).to(self.device)
+                if self.rng_mode == "replay" and u is None:
+                    nh, rows = self._host_rows(N)
+                    u = torch.empty(nh, Cm * HW, dtype=torch.float32).uniform_(0.0, 1.0)[rows].contiguous().to(self.device)
+                if u_out is not None:
+                    u_out.append(u)
         else:
             mask_in = mask_in.to(self.device, torch.float32).contiguous()
         call("mdm_degrade", ptr(img), ptr(u), ptr(mask_in), ptr(amt), 1, ptr(self.dev_rng.dev), rng_stream, N, C, HW,
@@ -225,6 +246,28 @@ class Scheduler:
     def degrade_with_mask(self, img, masks, mean_option, mean_area):
         x_t, _, _ = self._degrade(None, img, mean_option, mean_area, rng_stream=0, mask_in=masks, want_mask=False)
         return x_t
+
+    @staticmethod
+    def _check_dependent_args(args, mean_option, mean_area):
+        """What degrade_dependent_base_sampling runs for upstream (scheduler.py:480-549): 'thresholding' only (the 'indexing'
+        branch is `pass`, :490-491), and mean_option 'degraded_area' or the STRING "0" -- there is no float() attempt in that
+        function, so the int 0, numbers and 'non_degraded_area' leave mean_pixel_t unbound (D5)."""
+        if args.select_degrade_pixel != "thresholding":
+            raise UnboundLocalError("masks_t undefined: degrade_dependent_base_sampling has no 'indexing' branch (D5)")
+        if not ((mean_option == "degraded_area" and mean_area in ("image-wise", "channel-wise"))
+                or (isinstance(mean_option, str) and mean_option == "0")):
+            raise UnboundLocalError(f"mean_pixel_t undefined for mean_option={mean_option!r}, mean_area={mean_area!r} (D5)")
+
+    def degrade_dependent_base_sampling(self, black_area_num_t, black_area_num_next_t, img, mean_option, mean_area, _stream=3):
+        """scheduler.py:480-549: the masks of t and t-1 are NESTED -- one uniform draw per pixel thresholded at both
+        ratios -> (degraded_t, mask_t, mean_mask_t, degraded_next, mask_next, mean_mask_next).  Two launches of the degrade
+        kernel over the SAME uniforms: the host draw shipped once (replay), or the same Philox stream id (device)."""
+        self._check_dependent_args(self.args, mean_option, mean_area)
+        drawn = []
+        x_t, m_t, mp_t = self._degrade(black_area_num_t, img, mean_option, mean_area, rng_stream=_stream, u_out=drawn)
+        x_n, m_n, mp_n = self._degrade(black_area_num_next_t, img, mean_option, mean_area, rng_stream=_stream, u=drawn[0] if drawn else None)
+        ones = torch.ones_like(x_t)
+        return x_t, m_t, mp_t[:, :, None, None] * ones, x_n, m_n, mp_n[:, :, None, None] * ones
 
     # ---- shift -------------------------------------------------------------------------
     def _shift_draws(self, n, C, H, W, ratio_cpu):
@@ -260,7 +303,9 @@ class Scheduler:
             idx = (timesteps.int() - 1).to(self.device)
             ratio = torch.index_select(self.ratio_dev, 0, idx).contiguous()
             if self.rng_mode == "replay":
-                z = self._shift_draws(N, C, H, W, ratio.cpu()).to(self.device).contiguous()
+                nh, rows = self._host_rows(N)
+                rc = ratio.cpu()
+                z = self._shift_draws(nh, C, H, W, rc if nh == N else rc[:1].expand(nh))[rows].to(self.device).contiguous()
         # reference broadcast quirk: [N,*,H,W] * [N] lines up with the LAST axis when W == N (D10)
         per_col = int(self.reference_quirks and kind in (3, 4) and N == W and N > 1)
         s = torch.empty_like(x_t)

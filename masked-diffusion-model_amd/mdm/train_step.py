@@ -13,9 +13,14 @@ trainer_masked.py:95-183 (base == mean-shift with `shift_type=non_shift`, SURVEY
 Two ways to run it:
   run_replay(x0, used)  eager; all randomness drawn on the host in the reference's order
                         (parity with a reference run under the same seed);
-  run_device(x0, used)  device Philox; the step is three hipGraphs (forward+loss, backward chunks,
-                        optimizer) so that data-parallel ranks can all-reduce gradient buckets
-                        between backward chunks while the next chunk runs.
+  run_device(x0, used)  device Philox; ONE hipGraph per step on a single GPU; under data parallelism the
+                        backward is cut at the gradient-bucket boundaries (front / pieces / tail graphs) and
+                        each bucket's all-reduce is issued behind the piece that completes it.
+
+Gradient accumulation (`grad_accum` > 1; `accelerator.accumulate` + `sync_gradients` upstream, ms:139-172): a
+micro-step runs forward + loss (gradient scaled by 1 / grad_accum, what `accelerator.backward` does) + backward and
+adds its gradient buffer to `Gacc`; the step that syncs adds `Gacc` to its own gradient, exchanges (data parallel:
+one exchange per optimizer step, like DDP's no_sync), clips, updates and clears `Gacc`.
 """
 from __future__ import annotations
 
@@ -26,27 +31,49 @@ from ._lib import call, ptr, stream
 from .scheduler import SHIFT_KINDS, _fill_mode
 
 
+class LossCell:
+    """The step's loss as mdm_loss_fwd_bwd leaves it: two int64 words on the device, [0] = the mean loss in Q23.40 fixed point
+    (the workgroups' partial sums meet through integer atomics, which commute: the value is bit-identical run to run), [1] =
+    number of partials that were not representable.  `.item()` / `float()` synchronise and convert, like `loss.item()` upstream
+    (trainer_masked_mean_shift.py:193)."""
+
+    def __init__(self, device):
+        self.raw = torch.zeros(2, device=device, dtype=torch.int64)
+
+    def zero_(self):
+        self.raw.zero_()
+
+    def item(self):
+        q, bad = self.raw.tolist()
+        return float("nan") if bad else q * 2.0 ** -40
+
+    __float__ = item
+
+
 class TrainStep:
-    def __init__(self, model, scheduler, args, optimizer, ema=None, mean_shift=True, comm=None, max_norm=1.0):
+    def __init__(self, model, scheduler, args, optimizer, ema=None, mean_shift=True, comm=None, max_norm=1.0, grad_accum=1):
         self.model, self.S, self.args, self.opt, self.ema = model, scheduler, args, optimizer, ema
         self.mean_shift = mean_shift
         self.comm = comm                      # mdm.dist.GradComm or None
         self.max_norm = max_norm
+        self.grad_accum = int(grad_accum)
+        if self.grad_accum < 1:
+            raise ValueError(f"gradient_accumulation_steps={grad_accum}")
+        self.Gacc = torch.zeros_like(model.store.G) if self.grad_accum > 1 else None
         dev = model.device
         N, C, H, W = model.N, model.cin, model.H, model.W
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         self.x0, self.x_t, self.mask, self.s, self.x_in = f(N, C, H, W), f(N, C, H, W), f(N, C, H, W), f(N, C, H, W), f(N, C, H, W)
         self.mean_pixel = f(N, C)
         self.w = f(N)
-        self.loss = f(1)
+        self.loss = LossCell(dev)
         self.amount = torch.zeros(N, device=dev, dtype=torch.float64)
         self.ratio = torch.zeros(N, device=dev, dtype=torch.float64)
         self.tidx = torch.zeros(N, device=dev, dtype=torch.int32)
         self._used_key = None
         self._graphs = None
         self.use_graph = getattr(args, "use_graph", True)
-        self.overlap = bool(getattr(args, "overlap_wgrads", False))      # grouped weight gradients on a second stream
-        self.side = None
+        self.force_cut = bool(getattr(args, "cut_step_graph", False))    # single GPU: run the data-parallel (cut) form of the step
 
     # ---- pieces shared by both modes -------------------------------------------------------
     def _kind(self):
@@ -68,15 +95,16 @@ class TrainStep:
              ptr(m.x_in.data), m.cin_p, stream())
         m.forward_plan.run() if _lib._recording is None else _lib._recording.extend(m.forward_plan)
         call("mdm_loss_fwd_bwd", m.dt, ptr(m.y_out.data), ptr(self.x_in), ptr(self.s) if kind != 0 else None, ptr(self.x0),
-             ptr(self.w) if weights_on else None, N, C, H, W, m.cout_p, 1.0, ptr(m.y_out.grad), ptr(self.loss), stream())
+             ptr(self.w) if weights_on else None, N, C, H, W, m.cout_p, 1.0 / self.grad_accum, ptr(m.y_out.grad), ptr(self.loss.raw), stream())
 
     def _hyper(self):
         d = self.ema.next_decay() if self.ema is not None else 0.0
         self.opt.hyper(ema_decay=d)
 
     # ---- replay mode (parity) --------------------------------------------------------------
-    def run_replay(self, x0, used):
-        """Eager step with the reference's host RNG order. Returns the loss tensor."""
+    def run_replay(self, x0, used, sync=True):
+        """Eager step with the reference's host RNG order. Returns the loss cell.  `sync`: this micro-step
+        ends in the optimizer update (always, unless grad_accum > 1)."""
         m, S, a = self.model, self.S, self.args
         N, C, H, W = m.N, m.cin, m.H, m.W
         dev = m.device
@@ -111,8 +139,15 @@ class TrainStep:
         self._emit_forward_loss(u, z, mask_in, Cm, weights_on)
         m.store.G.zero_()
         m.run_backward()
-        self._finish_update()
         self.last = dict(timeindex=timeindex, t=t)
+        if self.grad_accum > 1 and not sync:
+            ops.add_(_lib.F32, self.Gacc, m.store.G)
+            return self.loss
+        if self.grad_accum > 1:
+            ops.add_(_lib.F32, m.store.G, self.Gacc)
+        self._finish_update()
+        if self.grad_accum > 1:
+            ops.fill(self.Gacc, 0.0)
         return self.loss
 
     def _finish_update(self):
@@ -154,7 +189,7 @@ class TrainStep:
         n_used = self.used_dev.numel()
         S.dev_rng.advance()                 # first launch of the step (part of the captured graph): a fresh Philox offset
         call("mdm_draw_timesteps", rng, ptr(self.used_dev), n_used, ptr(self.table_dev), ptr(self.wtab_dev), N,
-             ptr(m.t_in), ptr(self.amount), ptr(self.w), ptr(self.tidx), ptr(S.ratio_dev), ptr(self.ratio), ptr(self.loss), stream())
+             ptr(m.t_in), ptr(self.amount), ptr(self.w), ptr(self.tidx), ptr(S.ratio_dev), ptr(self.ratio), ptr(self.loss.raw), stream())
         mask_in, Cm = None, 1
         if a.select_degrade_pixel == "indexing":
             call("mdm_index_mask", ptr(self.amount), 1, rng, 1, N, C, H * W, ptr(self.mask), stream())
@@ -165,32 +200,15 @@ class TrainStep:
         m.emit_zero_grad()
 
     def _build_graphs(self):
-        """front = draws + degrade + shift + forward + loss; the backward is cut at every grouped weight-gradient launch
-        into [chain graph, group] pieces; tail = optimizer.  With `overlap` the groups are not part of any graph: each is
-        issued on a second stream as soon as the chain piece that produced its operands has been enqueued, so it runs
-        NEXT TO the following chain piece (hipGraph branches were measured NOT to run concurrently on this stack; two
-        streams do).  Data parallel: the bucket of a piece is all-reduced once its group has finished."""
+        """front = draws + degrade + shift + forward + loss + gradient zeroing; backward; tail = optimizer.
+        Single GPU, no accumulation: the whole step is ONE graph.  Data parallel: the backward launch list is cut behind
+        every grouped weight-gradient launch that completes a gradient bucket (`GradComm.plan_chunks`), one graph per piece,
+        and the bucket's all-reduce is issued behind its piece -- RCCL then runs on its own stream under the next piece.
+        (Running the grouped weight gradients themselves on a second stream was measured slower on this stack -- DESIGN
+        finding 16 -- and is gone.)  Accumulation: front / whole backward / tail graphs with the adds in between."""
         m = self.model
         with _lib.Recording() as front:
             self._emit_device_front()
-        calls = m.backward_plan.calls
-        is_group = lambda c: c[0] == "mdm_wgrad_group_launch"
-        # pieces: (chain calls, group call or None); bucket_after[j] = index of the bucket that is complete after piece j
-        pieces, lo = [], 0
-        for i, c in enumerate(calls):
-            if is_group(c):
-                pieces.append((calls[lo:i], c))
-                lo = i + 1
-        pieces.append((calls[lo:], None))
-        ends, pos = [], 0                       # number of calls consumed after each piece (group call included)
-        for chain, grp in pieces:
-            pos += len(chain) + (1 if grp is not None else 0)
-            ends.append(pos)
-        cuts = self.comm.plan_chunks(m) if self.comm is not None else []
-        self.bucket_after = {}
-        for b, c in enumerate(cuts):            # a bucket is complete after the first piece that ends at or behind its cut
-            j = next(k for k, e in enumerate(ends) if e >= c)
-            self.bucket_after.setdefault(j, []).append(b)
         with _lib.Recording() as tail:
             gmul = 1.0 / self.comm.world if self.comm is not None else 1.0
             self.opt.emit_update(self.ema.shadow if self.ema is not None else None, self.max_norm, gmul)
@@ -200,54 +218,65 @@ class TrainStep:
             r = _lib.Recording()
             r.calls, r.keep = list(cs), m.backward_plan.keep
             return r
-        if self.comm is None and not self.overlap:
-            # single GPU, serial: nothing happens between the pieces, so the whole step is ONE graph
+        calls = m.backward_plan.calls
+        if self.grad_accum > 1:
+            self._graphs = ("accum", mk(front), mk(rec(calls)), mk(tail))
+            return
+        if self.comm is None and not self.force_cut:
             whole = _lib.Recording()
             whole.extend(front); whole.extend(m.backward_plan); whole.extend(tail)
-            self._graphs = (mk(whole), [], None)
+            self._graphs = ("whole", mk(whole))
             return
-        if not self.overlap:                    # groups stay inside the chain graphs
-            built = [(mk(rec(list(chain) + ([grp] if grp is not None else []))), None) for chain, grp in pieces]
-        else:
-            built = [(mk(rec(chain)) if chain else None, grp) for chain, grp in pieces]
-            if self.side is None:
-                self.side = torch.cuda.Stream()
-                self.ev_main, self.ev_side = torch.cuda.Event(), torch.cuda.Event()
-        self._graphs = (mk(front), built, mk(tail))
+        # cut form: pieces end where a gradient bucket becomes complete (a cut index counts launches of the backward plan).
+        # `cut_step_graph` on a single GPU plans the same buckets a data-parallel run would (world = 1: no exchange), so
+        # that the price of cutting the step graph can be measured without a second GPU (bench.py --cut-graph)
+        from .dist import GradComm
+        planner = self.comm if self.comm is not None else GradComm()
+        cuts = sorted(set(min(c, len(calls)) for c in planner.plan_chunks(m)))
+        pieces, lo = [], 0
+        for b, c in enumerate(cuts):
+            pieces.append((mk(rec(calls[lo:c])) if c > lo else None, b))
+            lo = c
+        rest = mk(rec(calls[lo:])) if lo < len(calls) else None
+        self._graphs = ("cut", mk(front), pieces, rest, mk(tail))
 
-    def run_device(self, x0, used):
-        """Device-RNG step as hipGraph replays.  `x0` None = reuse the batch already in `self.x0`."""
+    def run_device(self, x0, used, sync=True):
+        """Device-RNG step as hipGraph replays.  `x0` None = reuse the batch already in `self.x0`.  `sync`: see run_replay."""
         if x0 is not None:
             self.x0.copy_(x0.to(torch.float32), non_blocking=True)
         self._upload_used(used)
         if self._graphs is None:
             self._build_graphs()
-        front, pieces, tail = self._graphs
-        self._hyper()
         go = (lambda g: g.launch()) if self.use_graph else (lambda g: g.run())
-        go(front)
-        if tail is None:
+        kind = self._graphs[0]
+        G = self.model.store.G
+        if kind == "accum":
+            _, front, bwd, tail = self._graphs
+            go(front); go(bwd)
+            if not sync:
+                ops.add_(_lib.F32, self.Gacc, G)
+                return self.loss
+            ops.add_(_lib.F32, G, self.Gacc)
+            if self.comm is not None:
+                self.comm.allreduce_all(G)
+            self._hyper()
+            go(tail)
+            ops.fill(self.Gacc, 0.0)
             return self.loss
-        main = torch.cuda.current_stream()
-        forked = False
-        for j, (chain, grp) in enumerate(pieces):
-            if chain is not None:
-                go(chain)
-            if grp is not None:                 # overlap: the group goes to the second stream, behind this chain piece
-                self.ev_main.record(main)
-                self.side.wait_event(self.ev_main)
-                _lib.check(grp[1](*grp[2], self.side.cuda_stream), grp[0])
-                forked = True
-            for b in (self.bucket_after.get(j, ()) if self.comm is not None else ()):
-                if grp is not None:
-                    with torch.cuda.stream(self.side):      # the exchange waits for the group, not for the chain
-                        self.comm.reduce_bucket(b, self.model.store.G)
-                else:
-                    self.comm.reduce_bucket(b, self.model.store.G)
-        if forked:
-            self.ev_side.record(self.side)
-            main.wait_event(self.ev_side)
+        self._hyper()
+        if kind == "whole":
+            go(self._graphs[1])
+            return self.loss
+        _, front, pieces, rest, tail = self._graphs
+        go(front)
+        for g, b in pieces:
+            if g is not None:
+                go(g)
+            if self.comm is not None:
+                self.comm.reduce_bucket(b, G)
+        if rest is not None:
+            go(rest)
         if self.comm is not None:
-            self.comm.wait_all(self.model.store.G)
+            self.comm.wait_all(G)
         go(tail)
         return self.loss

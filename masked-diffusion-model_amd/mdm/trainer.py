@@ -34,7 +34,8 @@ class Trainer:
         self.timesteps_used_epoch = None
         comm = GradComm(wire=getattr(args, "grad_wire_dtype", "f32")) if getattr(accelerator, "num_processes", 1) > 1 else None
         ema = ema_model if getattr(args, "use_ema", False) else None
-        self.step = TrainStep(model, self.Scheduler, args, optimizer, ema, mean_shift=self.mean_shift, comm=comm)
+        self.step = TrainStep(model, self.Scheduler, args, optimizer, ema, mean_shift=self.mean_shift, comm=comm,
+                              grad_accum=getattr(accelerator, "gradient_accumulation_steps", 1))
         self.loss_names = ["train_loss"]
         # what `accelerator.save_state(path)` / `load_state(path)` cover (main_train_masked.py:195-225 hooks)
         reg = getattr(accelerator, "register_for_checkpointing", None)
@@ -48,15 +49,23 @@ class Trainer:
         return input[0]
 
     def _step(self, input):
+        """ms:139-172.  `accelerator.accumulate` decides whether this micro-step syncs; clip + AdamW + EMA are one fused
+        launch inside the step and run only then.  The LR schedule advances only on a syncing step, and -- like accelerate's
+        AcceleratedScheduler, which the reference's `prepare()` at main_train_masked.py:299 wraps it in -- `num_processes`
+        times per optimizer step unless `split_batches`: schedules are written in single-process steps."""
         x0 = self._batch_images(input)
-        if self.Scheduler.rng_mode == "replay":
-            loss = self.step.run_replay(x0, self.timesteps_used_epoch)
-        else:
-            loss = self.step.run_device(x0, self.timesteps_used_epoch)
-        self.lr_scheduler.step()
-        if getattr(self.args, "use_ema", False):
-            pass                                  # EMA is folded into the optimizer kernel of the step
-        self.global_step += 1
+        acc = self.accelerator
+        with acc.accumulate(self.model):
+            sync = getattr(acc, "sync_gradients", True)
+            if self.Scheduler.rng_mode == "replay":
+                loss = self.step.run_replay(x0, self.timesteps_used_epoch, sync=sync)
+            else:
+                loss = self.step.run_device(x0, self.timesteps_used_epoch, sync=sync)
+            if sync:
+                for _ in range(1 if getattr(acc, "split_batches", False) else max(1, getattr(acc, "num_processes", 1))):
+                    self.lr_scheduler.step()
+        if sync:                                  # (EMA is folded into the optimizer kernel of the step)
+            self.global_step += 1
         self.learning_rate = self.lr_scheduler.get_last_lr()[0]
         self.lr_list.append(self.learning_rate)
         self.reconstruct_loss = loss
@@ -73,10 +82,18 @@ class Trainer:
         loss_batch = []
         self.timesteps_used_epoch = self.Scheduler.get_timesteps_epoch(epoch, epoch_length)
         for i, input in enumerate(self.dataloader, 0):
+            self._mark_end_of_dataloader(i)
             loss = self._run_batch(i, input, epoch, epoch_length, resume_step, dirs, visualizer)
             if self.accelerator.is_main_process:
                 loss_batch.append(loss)
         return loss_batch
+
+    def _mark_end_of_dataloader(self, i):
+        """accelerate's prepared dataloader flags its last batch, and `accumulate` syncs there whatever the micro-step
+        count is (Accelerator._do_sync); ours is told by the loop."""
+        n = len(self.dataloader) if hasattr(self.dataloader, "__len__") else None
+        if hasattr(self.accelerator, "end_of_dataloader"):
+            self.accelerator.end_of_dataloader = n is not None and i == n - 1
 
     def _epoch_losses(self, r):
         return r
@@ -142,6 +159,7 @@ class BaseTrainer(Trainer):
         out = ([], [], [])
         self.timesteps_used_epoch = self.Scheduler.get_timesteps_epoch(epoch, epoch_length)
         for i, input in enumerate(self.dataloader, 0):
+            self._mark_end_of_dataloader(i)
             r = self._run_batch(i, input, epoch, epoch_length, resume_step, dirs, visualizer)
             if self.accelerator.is_main_process:
                 for lst, v in zip(out, r):

@@ -463,8 +463,8 @@ class _Temb:
             return
         ops.matmul(F32, 2, ft, te, N, n.dT_all, ft, self.st_, te, n.fc_gw, te, acc=1, out_f32=1)
         ops.colsum(F32, n.dT_all, 1, N, ft, dbias=n.fc_gb)
-        ops.fill(d_st, 0.0)                                   # K = sum(Cout) ~ 5k against M = batch: split the reduction
-        ops.matmul(F32, 1, N, te, ft, n.dT_all, ft, n.fc_w, te, d_st, te, splitk=max(1, min(32, ft // 128)))
+        # K = sum(Cout) ~ 5k against M = batch: split the reduction (partial slabs in the workspace, summed in a fixed order)
+        ops.matmul(F32, 1, N, te, ft, n.dT_all, ft, n.fc_w, te, d_st, te, splitk=max(1, min(16, ft // 128)), ws=n.splitk_ws)
         ops.silu_bwd(self.tm, d_st, d_tm, 0, N * te)
         ops.matmul(F32, 2, te, te, N, d_tm, te, self.a1, te, st.g(self.l2 + ".weight"), te, acc=1, out_f32=1)
         ops.colsum(F32, d_tm, 1, N, te, dbias=st.g(self.l2 + ".bias"))
@@ -909,7 +909,10 @@ class UNet:
         self._graph_fwd.launch()
 
     def run_backward(self):
-        """y_out.grad must hold dL/dpred; parameter grads are ACCUMULATED into store.G."""
+        """y_out.grad must hold dL/dpred.  Gradient slots listed in `overwritten` (the grouped bf16 weight gradients, the
+        time-embedding weights) are STORED by this pass, every other slot (biases, GroupNorm scales, ungrouped weights) is
+        accumulated into and must have been cleared first (`emit_zero_grad`): two backward passes without an optimizer step
+        in between do NOT add up -- gradient accumulation goes through TrainStep, which sums whole gradient buffers."""
         self.backward_plan.run()
 
     def forward(self, x, t):

@@ -3,7 +3,8 @@
 Own-words restatement of /root/reference/code/sampler.py:46-83 (initial
 latent) and :109-261 (`_sample_mean_shift_momentum`), for the option values
 that run at HEAD: sampling_mask_dependency in {independent,
-dependent_prev}, momentum_adaptive in {base_sampling, base_momentum}.
+dependent_prev, dependent_t (thresholding with mean_option 'degraded_area' or "0")},
+momentum_adaptive in {base_sampling, base_momentum}.
 """
 from __future__ import annotations
 
@@ -81,8 +82,11 @@ class SamplerRef:
                     d_t = S.degrade_with_mask(x0_hat, m_next, mean_option=a.mean_option, mean_area=a.mean_area)
                     d_next, m_next, _ = S.degrade_independent_base_sampling(n_next, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area)
                     hist["degraded_mask"][slot] = m_next
+                elif dep == "dependent_t":                                  # :191-196
+                    d_t, m_t, _, d_next, m_next, _ = S.degrade_dependent_base_sampling(n_t, n_next, x0_hat, mean_option=a.mean_option, mean_area=a.mean_area)
+                    hist["degraded_mask"][slot] = m_t; hist["degraded_mask_next"][slot] = m_next
                 else:
-                    raise UnboundLocalError("sampling_mask_dependency=%r does not run upstream (D5)" % dep)
+                    raise UnboundLocalError("sampling_mask_dependency=%r is not an option upstream" % dep)
                 mode = a.momentum_adaptive
                 if mode == "base_sampling":                                 # :199-207
                     if i == 0:

@@ -327,6 +327,34 @@ class SchedulerRef:
     def degrade_with_mask(self, img, masks, mean_option, mean_area):
         return apply_degrade(img, masks, fill_value(img, masks, mean_option, mean_area))
 
+    def degrade_dependent_base_sampling(self, black_area_num_t, black_area_num_next_t, img, mean_option, mean_area):
+        """NESTED masks for t and t-1 from ONE uniform draw thresholded twice (scheduler.py:480-549).  Runs upstream only
+        for 'thresholding' (no 'indexing' branch, :490-491) and for mean_option 'degraded_area' or the STRING "0" (:514-535:
+        there is no float() attempt here, so the int 0 and every other value leave mean_pixel unbound)."""
+        a = self.args
+        n, c, hw = img.shape[0], img.shape[1], self.height * self.width
+        if a.select_degrade_pixel != "thresholding":
+            raise UnboundLocalError("masks_t undefined: degrade_dependent_base_sampling has no 'indexing' branch (D5)")
+        ch = getattr(a, "degrade_channel", None)
+        if ch == "1-channel":
+            u = self.rng.uniform((n, hw), 0.0, 1.0)
+            shape = lambda m: m.reshape(n, 1, self.height, self.width).expand(n, c, self.height, self.width)
+        elif ch == "3-channel":
+            u = self.rng.uniform((n, 3 * hw), 0.0, 1.0)
+            shape = lambda m: m.reshape(n, 3, self.height, self.width)
+        else:
+            raise UnboundLocalError("masks_t undefined for this degrade_channel (D8)")
+        m_t = shape((u > black_area_num_t.unsqueeze(1)).float())
+        m_next = shape((u > black_area_num_next_t.unsqueeze(1)).float())
+        if mean_option == "degraded_area" and mean_area in ("image-wise", "channel-wise"):
+            mp_t, mp_next = fill_value(img, m_t, mean_option, mean_area), fill_value(img, m_next, mean_option, mean_area)
+        elif isinstance(mean_option, str) and mean_option == "0":
+            mp_t = mp_next = torch.ones(n, c, 1, 1) * 0.0
+        else:
+            raise UnboundLocalError("mean_pixel_t undefined for mean_option=%r (D5)" % (mean_option,))
+        ones = torch.ones(n, m_t.shape[1], self.height, self.width)
+        return (apply_degrade(img, m_t, mp_t), m_t, mp_t * ones, apply_degrade(img, m_next, mp_next), m_next, mp_next * ones)
+
     def get_schedule_shift_time(self, timesteps, binarymasks):
         return shift_time(self.rng, self.args.shift_type, timesteps, self.ratio_list, binarymasks,
                           self.height, self.width, getattr(self.args, "noise_mean", 0.0),

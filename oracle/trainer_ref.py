@@ -22,10 +22,13 @@ def ema_decay(step, max_decay=0.9999, inv_gamma=1.0, power=0.75, min_decay=0.0, 
 
 
 def train_step_ref(model, opt, sched, args, x0, timesteps_used_epoch, rng, ema_params=None, ema_step=0,
-                   mean_shift=True, do_update=True):
+                   mean_shift=True, do_update=True, grad_scale=1.0, sync=True, zero=True):
     """Returns dict(loss, pred, x_t, mask, shift, x_in, recon, timeindex, t, grad_norm).
 
     Order of RNG draws: randint(timeindex) -> mask draw -> shift draws.
+    Gradient accumulation (`accelerator.accumulate`, ms:139-172): `grad_scale` = 1 / gradient_accumulation_steps is what
+    `accelerator.backward` multiplies the loss by, `zero` = this is the first micro-step after an update (the prepared
+    optimizer's zero_grad is skipped on non-syncing steps), `sync` = clip + optimizer step + EMA happen on this one.
     """
     n = x0.shape[0]
     x0 = x0.to(args.weight_dtype)
@@ -55,8 +58,11 @@ def train_step_ref(model, opt, sched, args, x0, timesteps_used_epoch, rng, ema_p
     out = dict(loss=loss.detach(), pred=pred.detach(), x_t=x_t, mask=masks, shift=s, x_in=x_in,
                recon=inv.detach(), timeindex=timeindex, t=t)
     if do_update:
-        opt.zero_grad()
-        loss.backward()
+        if zero:
+            opt.zero_grad()
+        (loss * grad_scale if grad_scale != 1.0 else loss).backward()
+        if not sync:
+            return out
         out["grad_norm"] = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)    # ms:163-164
         opt.step()
         if ema_params is not None:                                                    # ms:170-172
@@ -66,3 +72,35 @@ def train_step_ref(model, opt, sched, args, x0, timesteps_used_epoch, rng, ema_p
                     e.sub_((1 - d) * (e - p))
             out["ema_decay"] = d
     return out
+
+
+def train_loop_ref(model, opt, lr_sched, sched, args, dataloader, epoch_start, epoch_length, grad_accum=1, num_processes=1,
+                   split_batches=False, mean_shift=True):
+    """`Trainer.train()` / `_run_epoch` (trainer_masked_mean_shift.py:196-273) as a plain loop, with what accelerate's
+    prepared objects do around it (accelerate.Accelerator._do_sync, AcceleratedOptimizer, AcceleratedScheduler): a micro-step
+    syncs when its count reaches `grad_accum` or it is the last batch of the dataloader; the optimizer steps and is cleared
+    only then; the LR schedule steps only then, `num_processes` times unless `split_batches`.
+    -> dict(losses, sync, lr, used (per epoch), global_step)."""
+    args.updated_ddpm_num_steps = sched.update_ddpm_num_steps(args.ddpm_num_steps)
+    losses, syncs, lrs, used_all = [], [], [], []
+    global_step, micro = 0, 0
+    fresh = True
+    for epoch in range(epoch_start, epoch_start + epoch_length):
+        used = sched.get_timesteps_epoch(epoch, epoch_length)
+        used_all.append(list(used))
+        n = len(dataloader)
+        for i, batch in enumerate(dataloader):
+            if i == n - 1:
+                micro, sync = 0, True
+            else:
+                micro += 1
+                sync = micro % grad_accum == 0
+            r = train_step_ref(model, opt, sched, args, batch[0], used, sched.rng, mean_shift=mean_shift,
+                               grad_scale=1.0 / grad_accum, sync=sync, zero=fresh)
+            fresh = sync
+            if sync:
+                for _ in range(1 if split_batches else num_processes):
+                    lr_sched.step()
+                global_step += 1
+            losses.append(float(r["loss"])); syncs.append(sync); lrs.append(lr_sched.get_last_lr()[0])
+    return dict(losses=losses, sync=syncs, lr=lrs, used=used_all, global_step=global_step)

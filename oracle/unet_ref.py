@@ -157,7 +157,7 @@ def unet_forward(p, cfg, x, t):
     """unet6.py:478-506."""
     hid, mult, nres, attn = cfg["hid_channels"], cfg["ch_multipliers"], cfg["num_res_blocks"], cfg["apply_attn"]
     levels = len(mult)
-    temb = timestep_embedding(t, hid)
+    temb = timestep_embedding(t, hid).to(p["embed.0.weight"].dtype)     # (fp32 upstream; fp64 only for the yardstick runs below)
     temb = F.linear(temb, p["embed.0.weight"], p["embed.0.bias"])
     temb = F.linear(F.silu(temb), p["embed.2.weight"], p["embed.2.bias"])
 
@@ -192,12 +192,15 @@ class UNetRef(torch.nn.Module):
         def __init__(self, sample):
             self.sample = sample
 
-    def __init__(self, cfg, params=None, seed=1234):
+    def __init__(self, cfg, params=None, seed=1234, dtype=torch.float32):
+        """dtype=torch.float64: the same network in double precision -- the YARDSTICK the parity tests measure conditioning
+        with (how far the reference's own fp32 arithmetic is from the exact result on a given fixture), never a target."""
         super().__init__()
         self.cfg = dict(cfg)
+        self.dtype = dtype
         params = params if params is not None else random_params(cfg, seed)
         self.keys = list(params.keys())
-        self.plist = torch.nn.ParameterList([torch.nn.Parameter(params[k].clone().float()) for k in self.keys])
+        self.plist = torch.nn.ParameterList([torch.nn.Parameter(params[k].clone().to(dtype)) for k in self.keys])
 
     @property
     def device(self):
@@ -207,4 +210,4 @@ class UNetRef(torch.nn.Module):
         return {k: v for k, v in zip(self.keys, self.plist)}
 
     def forward(self, x, t):
-        return UNetRef._Out(unet_forward(self.pdict(), self.cfg, x.float(), t))
+        return UNetRef._Out(unet_forward(self.pdict(), self.cfg, x.to(self.dtype), t))

@@ -254,6 +254,44 @@ def gen_sampler(scheduler_mod, sampler_mod, unet6, out):
     out["samp_n"] = np.array(i)
 
 
+def gen_sampler_dep_t(scheduler_mod, sampler_mod, unet6, out):
+    """`sampling_mask_dependency='dependent_t'` (sampler.py:191-196 -> scheduler.py:480-549) for the sub-case that runs
+    upstream: thresholding, 1- or 3-channel masks, mean_option 'degraded_area' or the string "0"."""
+    i = 0
+    for mode in ("base_momentum", "base_sampling"):
+        for ch, kind, st, mo, ma in (("1-channel", "linear", "noise_with_perturbation", "0", "image-wise"),
+                                     ("3-channel", "exponential", "noise_reduction", "degraded_area", "channel-wise"),
+                                     ("1-channel", "linear", "1-d_constant", "degraded_area", "image-wise")):
+            a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=8, select_degrade_pixel="thresholding",
+                          degrade_channel=ch, shift_type=st, sampling_mask_dependency="dependent_t", momentum_adaptive=mode,
+                          sample_num=2, sample_latent_shape="uniform", mean_option=mo, mean_area=ma, noise_mean=0.05)
+            s = scheduler_mod.Scheduler(a); s.update_ddpm_num_steps(8)
+            ts = s.get_timesteps_epoch(0, 1)
+            model = _Wrap(build_ref_unet(unet6, TINY)).eval()
+            seed_all(800 + i)
+            x0, hist = sampler_mod.Sampler(None, a, s, [None] * 3).sample(model, ts)
+            out[f"dept{i}_cfg"] = np.array([mode, ch, kind, st, mo, ma])
+            out[f"dept{i}_ts"] = np.array(ts)
+            out[f"dept{i}_x0"] = npy(x0)
+            out[f"dept{i}_hist"] = np.stack([npy(h) for h in hist])
+            i += 1
+    out["dept_n"] = np.array(i)
+    # the combinations that do NOT run upstream: which exception they end in
+    for j, (sel, ch, mo) in enumerate((("thresholding", "1-channel", 0), ("thresholding", "1-channel", "non_degraded_area"),
+                                       ("indexing", None, "0"))):
+        a = base_args(data_size=16, ddpm_schedule="log", ddpm_num_steps=8, select_degrade_pixel=sel, degrade_channel=ch,
+                      shift_type="non_shift", sampling_mask_dependency="dependent_t", momentum_adaptive="base_momentum",
+                      sample_num=2, sample_latent_shape="zero", mean_option=mo)
+        s = scheduler_mod.Scheduler(a); s.update_ddpm_num_steps(8)
+        try:
+            sampler_mod.Sampler(None, a, s, [None] * 3).sample(_Wrap(build_ref_unet(unet6, TINY)).eval(), s.get_timesteps_epoch(0, 1))
+            err = "none"
+        except Exception as e:          # noqa: BLE001
+            err = type(e).__name__
+        out[f"dept_fail{j}"] = np.array([sel, str(ch), str(mo), type(mo).__name__, err])
+    out["dept_nfail"] = np.array(3)
+
+
 def gen_train_step(scheduler_mod, unet6, out):
     """One real `_run_batch` of each trainer with AdamW (main_train_masked.py:134-141)."""
     import accelerate
@@ -265,7 +303,8 @@ def gen_train_step(scheduler_mod, unet6, out):
     x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
     out["step_x0"] = npy(x0)
     watch = ["in_conv.weight", "out_conv.2.weight", "embed.2.bias", "middle.1.project_out.weight",
-             "upsamples.level_0.1.norm2.weight"]
+             "upsamples.level_0.1.norm2.weight", "in_conv.bias", "downsamples.level_0.0.conv1.weight", "downsamples.level_0.0.fc.weight",
+             "downsamples.level_1.0.0.skip.weight", "middle.0.norm1.bias", "upsamples.level_1.0.0.conv2.bias"]
     for name, mod, st, sel, ch, kind, lw in (
             ("ms", trainer_masked_mean_shift, "noise_with_perturbation", "thresholding", "1-channel", "linear", False),
             ("ms_w", trainer_masked_mean_shift, "1-d_constant", "thresholding", "3-channel", "exponential", True),
@@ -276,6 +315,15 @@ def gen_train_step(scheduler_mod, unet6, out):
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
         lr_s = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0)
         acc = accelerate.Accelerator(cpu=True)
+        grads = {}
+        orig = acc.clip_grad_norm_
+
+        def rec(params, max_norm, *aa, _m=model, _g=grads, _o=orig, **kk):      # the gradients as they stand BEFORE clipping
+            for k, v in _m.net.named_parameters():
+                _g[k] = v.grad.detach().clone()
+            _g["__norm__"] = _o(_m.parameters(), max_norm, *aa, **kk)
+            return _g["__norm__"]
+        acc.clip_grad_norm_ = rec
         if name == "base":
             class T(mod.Trainer):                      # constructor bypass
                 def __init__(self, args, model, opt, lr_s, acc):
@@ -298,6 +346,30 @@ def gen_train_step(scheduler_mod, unet6, out):
         sd = dict(model.net.named_parameters())
         for k in watch:
             out[f"step_{name}_w::{k}"] = npy(sd[k])
+        out[f"step_{name}_norm"] = np.array(float(grads.pop("__norm__")))
+        for k, v in grads.items():
+            out[f"step_{name}_g::{k}"] = npy(v)
+        # YARDSTICK: how far the reference's own fp32 gradients are from the exact ones on this fixture = rel-L2 against the
+        # oracle's step in fp64 on the same draws.  ('base' holds two fully degraded, all-zero inputs: GroupNorm sees variance
+        # exactly 0 there, rstd = 1/sqrt(eps) = 1000 multiplies every rounding error -- 3e-4 against ~1e-6 for the others.)
+        from oracle.scheduler_ref import SchedulerRef
+        from oracle.trainer_ref import train_step_ref
+        from oracle.unet_ref import UNetRef
+
+        class _NoOpt:
+            def zero_grad(self): pass
+            def step(self): pass
+        a64 = argparse.Namespace(**vars(a)); a64.weight_dtype = torch.float64
+        s64 = SchedulerRef(a64); s64.update_ddpm_num_steps(a.ddpm_num_steps)
+        m64 = UNetRef(TINY, dtype=torch.float64)
+        seed_all(500)
+        r64 = train_step_ref(m64, _NoOpt(), s64, a64, x0, tr.timesteps_used_epoch, s64.rng, mean_shift=(name != "base"))
+        assert np.allclose(npy(r64["x_in"]), out[f"step_{name}_xin"], rtol=0, atol=1e-6), "fp64 run saw other draws"
+        sc = min(1.0, 1.0 / (float(r64["grad_norm"]) + 1e-6))                   # undo the in-place clip
+        a_ = np.concatenate([(p_.grad / sc).numpy().reshape(-1) for p_ in m64.plist])
+        b_ = np.concatenate([npy(grads[k]).reshape(-1).astype(np.float64) for k in m64.keys])
+        out[f"step_{name}_g_yardstick"] = np.array(np.linalg.norm(a_ - b_) / np.linalg.norm(b_))
+        print(f"  step_{name}: fp32 reference vs fp64 gradients rel-L2 {float(out[f'step_{name}_g_yardstick']):.3e}")
 
 
 SLICE = dict(in_channels=3, hid_channels=256, out_channels=3, ch_multipliers=[1], num_res_blocks=1,
@@ -380,6 +452,113 @@ def gen_sampler_long(scheduler_mod, sampler_mod, unet6, out):
             out[f"long{i}_hist"] = h if T == 10 else h[:, ::10]
             i += 1
     out["long_n"] = np.array(i)
+
+
+def _describe(obj, prefix=""):
+    """Flat {path: 'kind dtype shape'} description of a nested checkpoint object: the key / shape / dtype GRAMMAR, no values."""
+    rows = {}
+    if isinstance(obj, torch.Tensor):
+        rows[prefix] = f"tensor {str(obj.dtype).replace('torch.', '')} {tuple(obj.shape)}"
+    elif isinstance(obj, np.ndarray):
+        rows[prefix] = f"ndarray {obj.dtype} {tuple(obj.shape)}"
+    elif isinstance(obj, dict):
+        if not obj:
+            rows[prefix] = "dict empty"
+        for k, v in obj.items():
+            rows.update(_describe(v, f"{prefix}/{k}" if prefix else str(k)))
+    elif isinstance(obj, (list, tuple)):
+        if len(obj) > 8 and all(isinstance(v, (int, float)) for v in obj):
+            rows[prefix] = f"{type(obj).__name__}[{len(obj)}] of {type(obj[0]).__name__}"
+        else:
+            if not obj:
+                rows[prefix] = f"{type(obj).__name__} empty"
+            for i, v in enumerate(obj):
+                rows.update(_describe(v, f"{prefix}/{i}"))
+    else:
+        rows[prefix] = type(obj).__name__
+    return rows
+
+
+def gen_train_traj(scheduler_mod, unet6, out):
+    """The reference's `MeanShiftTrainer.train()` END TO END (trainer_masked_mean_shift.py:196-273) on the tiny net: 2 epochs
+    x 3 batches of 4 through a real `accelerate.Accelerator(cpu=True)` whose `prepare()` wraps model, optimizer, dataloader
+    and LR schedule like main_train_masked.py:299 -- once with gradient_accumulation_steps = 1 and once with 2 (3 batches
+    per epoch: the last batch of an epoch syncs on the end-of-dataloader rule).  Stored: per-batch losses, the LR after every
+    batch, `timesteps_used_epoch` per epoch, global_step, all weights after training, and the key / shape / dtype
+    manifest of the `save_state` directory accelerate wrote (no hooks registered: main_train_masked.py's hooks need
+    diffusers, absent here)."""
+    import accelerate
+    import pickle
+    import trainer_masked_mean_shift as mod
+    from torch.utils.data import DataLoader, TensorDataset
+    g = torch.Generator().manual_seed(51)
+    data = torch.rand(12, 3, 16, 16, generator=g) * 2 - 1
+    out["traj_data"] = npy(data)
+    for gas in (1, 2):
+        tmp = tempfile.mkdtemp()
+        dirs = types.SimpleNamespace(list_dir={k: os.path.join(tmp, k) for k in ("train_loss", "checkpoint", "ema_sample_img")})
+        for d in dirs.list_dir.values():
+            os.makedirs(d)
+        a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=10, shift_type="noise_with_perturbation",
+                      loss_weight_use=True, batch_size=4, sample_num=2, sample_latent_shape="zero", use_ema=False,
+                      scheduler_num_scale_timesteps=2, save_images_epochs=10, gradient_accumulation_steps=gas)
+        seed_all(0)                                                        # main_train_masked.py:441-445
+        model = _Wrap(build_ref_unet(unet6, TINY))
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        lr_s = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0 / (1.0 + 0.25 * k))     # every scheduler step is visible
+        loader = DataLoader(TensorDataset(data, torch.zeros(12)), batch_size=4, shuffle=False)
+        acc = accelerate.Accelerator(cpu=True, gradient_accumulation_steps=gas)
+        model, opt, loader, lr_s = acc.prepare(model, opt, loader, lr_s)
+        tr = mod.Trainer(a, loader, None, [None] * 3, model, None, opt, lr_s, acc)
+        losses, used, ts_batch, syncs = [], [], [], []
+        orig_batch, orig_epoch = tr._run_batch, tr._run_epoch
+
+        def run_batch(*aa, **kk):
+            r = orig_batch(*aa, **kk)
+            losses.append(r); syncs.append(bool(acc.sync_gradients))
+            return r
+
+        def run_epoch(*aa, **kk):
+            r = orig_epoch(*aa, **kk)
+            used.append(list(tr.timesteps_used_epoch))
+            return r
+        tr._run_batch, tr._run_epoch = run_batch, run_epoch
+        seed_all(900 + gas)
+        tr.train(0, 2, 0, 0, dirs, None)
+        tag = f"traj_g{gas}"
+        out[tag + "_losses"] = np.array(losses, dtype=np.float64)
+        out[tag + "_sync"] = np.array(syncs)
+        out[tag + "_lr"] = np.array(tr.lr_list, dtype=np.float64)
+        out[tag + "_global_step"] = np.array(tr.global_step)
+        out[tag + "_used_e0"] = np.array(used[0]); out[tag + "_used_e1"] = np.array(used[1])
+        net = acc.unwrap_model(model).net
+        for k, v in net.named_parameters():
+            out[tag + "_w::" + k] = npy(v)
+        # ---- what accelerate's save_state wrote (trainer_masked_mean_shift.py:267-269)
+        ck = os.path.join(dirs.list_dir["checkpoint"], "checkpoint-epoch-1")
+        files = sorted(os.listdir(ck))
+        out[tag + "_ckpt_dirs"] = np.array(sorted(os.listdir(dirs.list_dir["checkpoint"])))
+        out[tag + "_ckpt_files"] = np.array(files)
+        rows = {}
+        for f in files:
+            path = os.path.join(ck, f)
+            if f.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                rows.update(_describe(load_file(path), f))
+            elif f.endswith(".bin") or f.endswith(".pkl"):        # (random_states_<rank>.pkl is a torch.save file too)
+                rows.update(_describe(torch.load(path, map_location="cpu", weights_only=False), f))
+        keys = sorted(rows)
+        out[tag + "_ckpt_manifest"] = np.array([f"{k} :: {rows[k]}" for k in keys])
+        if gas == 1:           # the optimizer state values, to check a load of OUR optimizer.bin against (exp_avg of two tensors + step)
+            osd = torch.load(os.path.join(ck, "optimizer.bin"), map_location="cpu", weights_only=False)
+            out["traj_g1_opt_step"] = np.array(float(osd["state"][0]["step"]))
+            out["traj_g1_opt_exp_avg_0"] = npy(osd["state"][0]["exp_avg"])
+            out["traj_g1_opt_exp_avg_sq_5"] = npy(osd["state"][5]["exp_avg_sq"])
+            out["traj_g1_opt_group"] = np.array([f"{k}={v}" for k, v in osd["param_groups"][0].items() if k != "params"])
+            ssd = torch.load(os.path.join(ck, "scheduler.bin"), map_location="cpu", weights_only=False)
+            out["traj_g1_sched"] = np.array([f"{k}={v}" for k, v in ssd.items()])
+        print(f"  traj gas={gas}: losses {np.round(losses, 4).tolist()} sync {syncs} lr {np.round(tr.lr_list, 6).tolist()} "
+              f"global_step {tr.global_step} files {files}")
 
 
 def gen_train_grads(scheduler_mod, unet6, out):
@@ -469,6 +648,8 @@ def main():
         "blocks": lambda o: gen_blocks(unet6, o),
         "sampler_long": lambda o: gen_sampler_long(scheduler_mod, sampler_mod, unet6, o),
         "train_grads": lambda o: gen_train_grads(scheduler_mod, unet6, o),
+        "sampler_dep_t": lambda o: gen_sampler_dep_t(scheduler_mod, sampler_mod, unet6, o),
+        "train_traj": lambda o: gen_train_traj(scheduler_mod, unet6, o),
         "evaluate": lambda o: gen_evaluate(scheduler_mod, sampler_mod, o),
     }
     only = sys.argv[1:]

@@ -358,12 +358,14 @@ def test_batched_matmul_layouts(dt, shape):
                    sD=M * N, alpha=0.25)
         torch.cuda.synchronize()
         assert _relerr(D, want) < _tol(dt), f"layout {layout}"
-    # layout 2 with split-K into an fp32 destination that already holds a value
-    D = torch.full((B, M, N), 1.0, device=dev, dtype=torch.float32)
-    ops.matmul(DT[dt], 2, M, N, K, _up(a_km, dt), M, _up(b_kn, dt), N, D, N, batch=B, sA=M * K, sB=N * K, sD=M * N,
-               alpha=0.25, out_f32=1, splitk=2)
-    torch.cuda.synchronize()
-    assert _relerr(D - 1.0, want) < _tol(dt)
+    # layout 2 with split-K (partial slabs in a workspace, summed in a fixed order) ACCUMULATED onto an fp32 destination;
+    # and the same request without a workspace: the reduction is then not split (there is no atomic fallback)
+    for ws in (torch.empty(2 * B * M * N, device=dev, dtype=torch.float32), None):
+        D = torch.full((B, M, N), 1.0, device=dev, dtype=torch.float32)
+        ops.matmul(DT[dt], 2, M, N, K, _up(a_km, dt), M, _up(b_kn, dt), N, D, N, batch=B, sA=M * K, sB=N * K, sD=M * N,
+                   alpha=0.25, out_f32=1, splitk=2, acc=1, ws=ws)
+        torch.cuda.synchronize()
+        assert _relerr(D - 1.0, want) < _tol(dt)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -171,6 +171,41 @@ def test_sampler_trajectories(golden):
         assert np.allclose(x0.numpy(), g[f"samp{i}_x0"], rtol=1e-4, atol=5e-5)
 
 
+def test_sampler_dependent_t(golden):
+    """`sampling_mask_dependency='dependent_t'` (sampler.py:191-196, scheduler.py:480-549): nested masks from one draw;
+    and the combinations that fail upstream fail the same way."""
+    g = golden("sampler_dep_t")
+    for i in range(int(g["dept_n"])):
+        mode, ch, kind, st, mo, ma = [str(v) for v in g[f"dept{i}_cfg"]]
+        a = base_args(data_size=16, ddpm_schedule=kind, ddpm_num_steps=8, select_degrade_pixel="thresholding", degrade_channel=ch,
+                      shift_type=st, sampling_mask_dependency="dependent_t", momentum_adaptive=mode, sample_num=2,
+                      sample_latent_shape="uniform", mean_option=mo, mean_area=ma, noise_mean=0.05)
+        s = S.SchedulerRef(a)
+        s.update_ddpm_num_steps(8)
+        ts = s.get_timesteps_epoch(0, 1)
+        assert ts == list(g[f"dept{i}_ts"])
+        seed_all(800 + i)
+        x0, hist = SamplerRef(None, a, s, [None] * 3).sample(UNetRef(TINY).eval(), ts)
+        ref = g[f"dept{i}_hist"]
+        assert np.array_equal(hist[1].numpy(), ref[1]), (i, "shift")
+        assert np.array_equal(hist[6].numpy(), ref[6]) and np.array_equal(hist[7].numpy(), ref[7]), (i, "masks")
+        assert (hist[6].numpy() <= hist[7].numpy()).all(), "mask_t must be nested inside mask_{t-1}"
+        for j in range(11):
+            assert np.allclose(hist[j].numpy(), ref[j], rtol=1e-4, atol=5e-5, equal_nan=True), (i, j)
+        assert np.allclose(x0.numpy(), g[f"dept{i}_x0"], rtol=1e-4, atol=5e-5, equal_nan=True)
+    for j in range(int(g["dept_nfail"])):
+        sel, ch, mo, mo_type, err = [str(v) for v in g[f"dept_fail{j}"]]
+        mo = int(mo) if mo_type == "int" else mo
+        a = base_args(data_size=16, ddpm_schedule="log", ddpm_num_steps=8, select_degrade_pixel=sel,
+                      degrade_channel=None if ch == "None" else ch, shift_type="non_shift", sampling_mask_dependency="dependent_t",
+                      momentum_adaptive="base_momentum", sample_num=2, sample_latent_shape="zero", mean_option=mo)
+        s = S.SchedulerRef(a)
+        s.update_ddpm_num_steps(8)
+        with pytest.raises(Exception) as ei:
+            SamplerRef(None, a, s, [None] * 3).sample(UNetRef(TINY).eval(), s.get_timesteps_epoch(0, 1))
+        assert type(ei.value).__name__ == err, (j, type(ei.value).__name__, err)
+
+
 # ----------------------------------------------------------------------------- train step
 @pytest.mark.parametrize("name", ["ms", "ms_w", "base"])
 def test_train_step(golden, name):
@@ -194,6 +229,46 @@ def test_train_step(golden, name):
         if k.startswith(f"step_{name}_w::"):
             # one AdamW step moves every weight by ~lr regardless of gradient scale, so compare tightly
             assert np.allclose(sd[k.split("::")[1]].detach().numpy(), g[k], rtol=0, atol=2e-5), k
+
+
+@pytest.mark.parametrize("gas", [1, 2])
+def test_train_trajectory(golden, gas):
+    """The reference's `train()` run end to end through real accelerate objects (make_golden.gen_train_traj): 2 epochs x 3
+    batches, gradient accumulation 1 and 2 -- the oracle's loop reproduces losses, sync pattern, LR after every batch,
+    timestep subsets, global_step and the final weights."""
+    from oracle.trainer_ref import train_loop_ref
+    from torch.utils.data import DataLoader, TensorDataset
+    g = golden("train_traj")
+    data = T(g["traj_data"])
+    a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=10, shift_type="noise_with_perturbation",
+                  loss_weight_use=True, batch_size=4, use_ema=False, scheduler_num_scale_timesteps=2, gradient_accumulation_steps=gas)
+    model = UNetRef(TINY)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    lr_s = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: 1.0 / (1.0 + 0.25 * k))
+    loader = DataLoader(TensorDataset(data, torch.zeros(12)), batch_size=4, shuffle=False)
+    s = S.SchedulerRef(a)
+    seed_all(900 + gas)
+    r = train_loop_ref(model, opt, lr_s, s, a, loader, 0, 2, grad_accum=gas)
+    tag = f"traj_g{gas}"
+    assert r["sync"] == list(g[tag + "_sync"]) and r["global_step"] == int(g[tag + "_global_step"])
+    assert r["used"] == [list(g[tag + "_used_e0"]), list(g[tag + "_used_e1"])]
+    assert np.allclose(r["lr"], g[tag + "_lr"], rtol=1e-12)
+    assert np.allclose(r["losses"], g[tag + "_losses"], rtol=2e-5), (r["losses"], g[tag + "_losses"])
+    sd = model.pdict()
+    live = live_gradient_keys(golden("train_step"))
+    assert len(live) > 100
+    for k in live:
+        assert np.allclose(sd[k].detach().numpy(), g[tag + "_w::" + k], rtol=0, atol=5e-5), k
+
+
+def live_gradient_keys(gs, name="ms"):
+    """Parameters of TINY whose gradient is not mathematically zero.  A bias or time-embedding projection in front of a
+    GroupNorm with ONE channel per group (TINY's 32-channel level) has none: its measured gradient is rounding noise
+    (rms ~1e-9 against ~1e-3), and AdamW turns that noise into +-lr per step on both sides -- such tensors carry no parity
+    information after an update.  Read off the reference's own gradients of one step (tests/golden/train_step.npz)."""
+    rms = {k.split("::")[1]: float(np.sqrt((gs[k] ** 2).mean())) for k in gs.files if k.startswith(f"step_{name}_g::")}
+    med = sorted(rms.values())[len(rms) // 2]
+    return [k for k, v in rms.items() if v > 1e-3 * med]
 
 
 # ----------------------------------------------------------------------------- round-2 fixtures (tests/golden/make_golden.py: blocks, sampler_long, train_grads)
