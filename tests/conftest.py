@@ -14,6 +14,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle (torch on the CPU) is the slow side of the long sampler tests.  A GPU box shows all of the host's cores but
+    # gives one GPU a 16-core share: torch's default thread count oversubscribes it ~10x (a 250-step oracle run took 25 s there
+    # against 2.5 s on 8 threads here).
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, n)))
 
 
 @pytest.fixture(scope="session")
