@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace mdm {
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 // of one pixel: residual, accumulate and the store are 16-byte accesses, 256 B contiguous per 16 lanes.
 // Rounding happens once, after every fp32 term is in -- same arithmetic as epilogue4.
 // ----------------------------------------------------------------------------
-template <int BM, int BN, int NW, int MI, int NI>
+template <int BM, int BN, int NW, int MI, int NI, typename T = bf16_t>
 __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
                                               int lane, int t, f32x4 (&acc)[MI][NI]) {
     constexpr int PITCH = BN * 4;
@@ -1138,13 +1139,13 @@ __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds,
         const float4 hi = *reinterpret_cast<const float4*>(lds + r * PITCH + (((2 * q + 1) ^ (r & 7)) << 4));
         float8 v = {lo, hi};
         if (d.resid) {
-            float8 b = load8(reinterpret_cast<const bf16_t*>(d.resid) + (int64_t)m * d.ldr + n);
+            float8 b = load8(reinterpret_cast<const T*>(d.resid) + (int64_t)m * d.ldr + n);
             v.lo.x += b.lo.x; v.lo.y += b.lo.y; v.lo.z += b.lo.z; v.lo.w += b.lo.w;
             v.hi.x += b.hi.x; v.hi.y += b.hi.y; v.hi.z += b.hi.z; v.hi.w += b.hi.w;
         }
-        bf16_t* p; int accf;
-        if (n < d.N0) { p = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n; accf = d.acc0; }
-        else          { p = reinterpret_cast<bf16_t*>(d.D1) + (int64_t)m * d.ldd1 + (n - d.N0); accf = d.acc1; }
+        T* p; int accf;
+        if (n < d.N0) { p = reinterpret_cast<T*>(d.D0) + (int64_t)m * d.ldd0 + n; accf = d.acc0; }
+        else          { p = reinterpret_cast<T*>(d.D1) + (int64_t)m * d.ldd1 + (n - d.N0); accf = d.acc1; }
         if (accf) {
             float8 o = load8(p);
             v.lo.x += o.lo.x; v.lo.y += o.lo.y; v.lo.z += o.lo.z; v.lo.w += o.lo.w;
@@ -2018,7 +2019,20 @@ template <int NPW, int APT, int D, int TG> constexpr int halo_vmcnt(int g) {    
 // per tap, the price of the barrier + wait + the filter-fragment round trip.  The halo pieces of the next channel
 // slab are dealt out APT per group over the first groups, so that they are all older than the filter tiles the
 // first group of that slab waits for.
-template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
+__device__ __forceinline__ void halo_mma(f32x4& acc, const bf16x8& b, const bf16x8& a) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void halo_mma(f32x4& acc, const float4& b, const float4& a) {      // 16 k: four exact-fp32 MFMAs
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a.w, acc, 0, 0, 0);
+}
+// T = bf16_t: v_mfma_f32_16x16x32_bf16 on 64-channel slabs.  T = float (the exact-fp32 path: the reverse sampler of record): the SAME
+// tile, halo, ring and offset tables in bytes -- a 128-byte halo row is then 32 channels, a lane's 16-byte fragment is 4 consecutive
+// k that feed four v_mfma_f32_16x16x4_f32 (lane group g supplies k = 4 g + j to MFMA j on both operands, as in gemm_f32_mfma_kernel).
+// At a sixteenth of the bf16 matrix rate the loop, not the prologue / epilogue / LDS, sets the time: the kernel is MFMA-bound.
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t>
 __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
     constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
     constexpr int NG = 9 / TG;                                    // groups per channel slab
@@ -2027,6 +2041,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     static_assert(9 % TG == 0 && D >= 1 && D < NG && APT * (NG - D) >= NPW, "conv_halo: halo pieces do not fit in front of the refill distance");
     static_assert(MI >= 1 && NI >= 1, "conv_halo: tile too small for 4 x 2 waves");
     constexpr int B_BYTES = BN * 128, STAGE_B = TG * B_BYTES;
+    constexpr int KC = 128 / (int)sizeof(T);                    // channels per slab (one 128-byte halo row)
+    constexpr bool F32 = sizeof(T) == 4;
+    typedef typename std::conditional<F32, float4, bf16x8>::type Frag;
     MDM_T(const unsigned long long t_entry = stamp_now();)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -2053,7 +2070,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
     const int img = m0 >> p_sh, y0 = (m0 >> ow_sh) & (OH - 1);
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
-    const int NCS = d.Ck / 64;                       // 64-channel slabs over both sources
+    const int NCS = d.Ck / KC;                       // channel slabs over both sources
     const int sgn = d.transposed ? -1 : 1;
 
     // ---- halo pieces of this wave: piece p = wave + 8 k holds halo rows 8p .. 8p+7
@@ -2071,9 +2088,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     }
     auto issue_a = [&](int k, int cs, char* abuf) {                 // k compile-time after unrolling
         const int p = wave + 8 * k;
-        const int c = cs * 64;
+        const int c = cs * KC;
         const bool s1 = c >= d.C0;
-        const bf16_t* S = reinterpret_cast<const bf16_t*>(s1 ? d.src1 : d.src0);
+        const T* S = reinterpret_cast<const T*>(s1 ? d.src1 : d.src0);
         const int ld = s1 ? d.ld1 : d.ld0, cc = s1 ? c - d.C0 : c;
         const char* src = reinterpret_cast<const char*>(S + (int64_t)apix[k] * ld + cc) + lch16;
         lds_dma16((apix[k] >= 0 && cs < NCS) ? src : zlane, p < NPA ? abuf + p * 1024 : dummy);
@@ -2082,9 +2099,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     // issue into the dummy page so that every wave counts the same number of DMA operations)
     const bool b_wave = wave * 8 < BN;
     const int bn = n0 + (b_wave ? wave * 8 : 0) + (lane >> 3);
-    const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)bn * d.ldb) + lch16;
+    const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const T*>(d.B) + (int64_t)bn * d.ldb) + lch16;
     auto issue_b = [&](int tap, int cs, int lds_off) {               // lds_off: byte offset of the tile inside the ring
-        const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * 64) * 2;
+        const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * KC) * (int64_t)sizeof(T);
         lds_dma16((cs < NCS && b_wave) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
     };
 
@@ -2142,29 +2159,29 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
         }                                                                                                        \
         const char* As = lds + a_cur;                                                                            \
         const char* Bs = bring + b_stage * STAGE_B + ((T) % TG) * B_BYTES;                                       \
-        bf16x8 bfr[2][NI];                                                                                       \
+        Frag bfr[2][NI];                                                                                         \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
-                bfr[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + b_off[ks][j]);                                \
+                bfr[ks][j] = *reinterpret_cast<const Frag*>(Bs + b_off[ks][j]);                                  \
         if ((T) == 0) {            /* a new halo buffer: its fragments can only be read behind this barrier */   \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-                    afr[0][ks][i] = *reinterpret_cast<const bf16x8*>(As + (a_addr[0][i] ^ (ks << 6)));           \
+                    afr[0][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[0][i] ^ (ks << 6)));             \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], afr[(T) & 1][0][i], acc[i][j], 0, 0, 0); \
+                halo_mma(acc[i][j], bfr[0][j], afr[(T) & 1][0][i]);                                              \
         if ((T) < 8) {             /* the next tap reads the SAME halo buffer at shifted rows: fetch it now */    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-                    afr[((T) + 1) & 1][ks][i] = *reinterpret_cast<const bf16x8*>(As + (a_addr[((T) + 1) % 9][i] ^ (ks << 6))); \
+                    afr[((T) + 1) & 1][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[((T) + 1) % 9][i] ^ (ks << 6))); \
         }                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], afr[(T) & 1][1][i], acc[i][j], 0, 0, 0); \
+                halo_mma(acc[i][j], bfr[1][j], afr[(T) & 1][1][i]);                                              \
         if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
-    bf16x8 afr[2][2][MI];                  // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
+    Frag afr[2][2][MI];                    // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
     MDM_T(const unsigned long long tstart = stamp_now();)
     const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
     for (int cs = 0; cs < NCS; ++cs) {
@@ -2176,12 +2193,12 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     wait_vmcnt<0>();
     MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
-    if constexpr (BM == 64 && (BN == 64 || BN == 32)) {
+    if constexpr (!F32 && BM == 64 && (BN == 64 || BN == 32)) {
         if (d.gnb_x) epilogue_tile_gnb<MI, NI, BN>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
         else if (d.gnf_out) epilogue_tile_gnf<MI, NI, BN>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
         else epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
-        epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        epilogue_tile<BM, BN, NW, MI, NI, T>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
     }
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2196,10 +2213,10 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 #endif
 }
 
-template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1>
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t>
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    conv_halo_body<BM, NPW, BN, NSB, TG>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+    conv_halo_body<BM, NPW, BN, NSB, TG, T>(d, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // TWO independent convolutions in one launch (mdm_gemm_pair): workgroups [0, na) run the 3x3 halo convolution `a`, the rest
@@ -2324,7 +2341,7 @@ static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of on
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW, int NSB, int BN = 64>
+template <int BM, int NPW, int NSB, int BN = 64, typename T = bf16_t>
 static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filter row (3 taps) per barrier
     constexpr int TG = 3;
     const int NPA = halo_pieces(BM, d.OH, d.OW);
@@ -2334,12 +2351,12 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filt
     MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
     static int configured = 0;
     if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN, NSB, TG>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN, NSB, TG, T>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
     dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / BN)));
-    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG>), grid, dim3(512), bytes, s, d);
+    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T>), grid, dim3(512), bytes, s, d);
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
@@ -2362,6 +2379,32 @@ static int halo_tile(const mdm_gemm_desc& d) {
     // replaces the tap-split conv + its epilogue launch, and the tile holds whole images (GroupNorm-fusable)
     // (4x4 maps with > 256 input channels: level with the tap-split conv + its epilogue launch since the tiles are 32 channels
     //  wide -- 3.977 vs 3.976 ms/step -- and six launches fewer)
+    if ((d.OW == 4 || d.OW == 8) && d.OH == d.OW && 64 % (d.OH * d.OW) == 0 && d.M % 64 == 0) return 64;
+    return 0;
+}
+
+// The exact-fp32 path on the halo kernel (conv_halo_body<..., float>): 0 = not eligible, else the pixel tile.  Same geometry
+// rules as halo_tile; channel counts in 32-channel slabs.  The fp32 loop is MFMA-bound, so the tile is picked for the fewest
+// idle slots in the last round of workgroups (one workgroup per CU): at sample_num = 100 a 32x32 layer is 800 tiles of 256 pixels
+// (3.1 rounds: 78 % of the slots busy) or 1600 of 128 (6.25 rounds: 89 %).
+static int halo_tile_f32(const mdm_gemm_desc& d) {
+    if (!(d.dtype == MDM_F32 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && (d.ups == 0 || d.ups == 1) &&
+          !(d.ups && (d.transposed || d.C1)) && d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW &&
+          d.C0 % 32 == 0 && d.C1 % 32 == 0 && d.Ck == d.C0 + d.C1 && d.N % 64 == 0 && d.N0 % 8 == 0 && d.splitk <= 1 &&
+          (d.OH & (d.OH - 1)) == 0 && (d.OW & (d.OW - 1)) == 0))
+        return 0;
+    if (d.OW == 16 || d.OW == 32 || d.OW == 64) {
+        int best = 0;
+        double best_eff = 0.0;
+        for (int bm : {256, 128}) {
+            if (bm % d.OW || d.OH % (bm / d.OW) || d.M % bm) continue;
+            if (halo_pieces(bm, d.OH, d.OW) > 48) continue;
+            const int64_t tiles = (int64_t)(d.M / bm) * (d.N / 64);
+            const double eff = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = bm; }
+        }
+        return best;
+    }
     if ((d.OW == 4 || d.OW == 8) && d.OH == d.OW && 64 % (d.OH * d.OW) == 0 && d.M % 64 == 0) return 64;
     return 0;
 }
@@ -2537,6 +2580,13 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             configured = true;
         }
         hipLaunchKernelGGL(linear_skinny_f32_kernel, dim3((unsigned)cdiv(d.N, 16)), dim3(256), bytes, s, d);
+    } else if (const int hb32 = halo_tile_f32(d)) {
+        // exact-fp32 3x3 convolutions on the halo kernel (forward, folded upsample, transposed shadow): MFMA-bound
+        const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
+        if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, 2, 64, float>(d, s) : launch_halo<256, 6, 2, 64, float>(d, s);
+        else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float>(d, s)
+                                                                                         : launch_halo<128, 6, 3, 64, float>(d, s);
+        else rc = npw <= 2 ? launch_halo<64, 2, 3, 64, float>(d, s) : launch_halo<64, 3, 3, 64, float>(d, s);
     } else if (d.dtype == MDM_F32) {
         // exact-fp32 MFMA kernel; 128 x 128 tiles when that still gives about one workgroup per CU
         const bool big32 = d.M >= 128 && d.N >= 128 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * grid.z >= kBigMinTiles;
