@@ -2019,14 +2019,27 @@ template <int NPW, int APT, int D, int TG> constexpr int halo_vmcnt(int g) {    
 // per tap, the price of the barrier + wait + the filter-fragment round trip.  The halo pieces of the next channel
 // slab are dealt out APT per group over the first groups, so that they are all older than the filter tiles the
 // first group of that slab waits for.
-__device__ __forceinline__ void halo_mma(f32x4& acc, const bf16x8& b, const bf16x8& a) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
+// acc[i][j] += B-fragment j x A-fragment i over one k-step (32 bf16 k, or 16 fp32 k as four 16x16x4 MFMAs with the k index
+// OUTERMOST: consecutive MFMAs then write different accumulators, none waits for the one in front of it)
+template <int MI, int NI>
+__device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const bf16x8 (&b)[NI], const bf16x8 (&a)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 }
-__device__ __forceinline__ void halo_mma(f32x4& acc, const float4& b, const float4& a) {      // 16 k: four exact-fp32 MFMAs
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a.w, acc, 0, 0, 0);
+template <int MI, int NI>
+__device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const float4 (&b)[NI], const float4 (&a)[MI]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const float bv = c == 0 ? b[j].x : c == 1 ? b[j].y : c == 2 ? b[j].z : b[j].w;
+                const float av = c == 0 ? a[i].x : c == 1 ? a[i].y : c == 2 ? a[i].z : a[i].w;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+            }
 }
 // T = bf16_t: v_mfma_f32_16x16x32_bf16 on 64-channel slabs.  T = float (the exact-fp32 path: the reverse sampler of record): the SAME
 // tile, halo, ring and offset tables in bytes -- a 128-byte halo row is then 32 channels, a lane's 16-byte fragment is 4 consecutive
@@ -2145,6 +2158,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 
     int a_cur = 0;                         // byte offset of the halo buffer being multiplied
     int b_stage = 0;                       // ring stage of the current tap-slab
+    const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
 #define MDM_HALO_TAP(T)                                                                                          \
     {                                                                                                            \
         if ((T) % TG == 0) {                                                                                     \
@@ -2152,6 +2166,8 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
             wait_vmcnt<halo_vmcnt<NPW, APT, D, TG>((T) / TG)>();                                                 \
             __builtin_amdgcn_s_barrier();                                                                        \
             const int rs = b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D;                                 \
+            /* (dealing these DMA pieces out between the MFMAs of the tap, as conv_lin2 does, changed neither the  \
+               bf16 step -- 3.904 vs 3.908 ms -- nor the fp32 sampler -- 14.38 vs 14.37 s: measured, not kept) */  \
             _Pragma("unroll") for (int k = 0; k < TG; ++k)                                                       \
                 issue_b((((T) / TG + D) % NG) * TG + k, cs + ((T) / TG + D) / NG, rs * STAGE_B + k * B_BYTES);   \
             _Pragma("unroll") for (int q = 0; q < APT; ++q)                                                      \
@@ -2168,22 +2184,17 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
                     afr[0][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[0][i] ^ (ks << 6)));             \
         }                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
-                halo_mma(acc[i][j], bfr[0][j], afr[(T) & 1][0][i]);                                              \
+        halo_mma_tile<MI, NI>(acc, bfr[0], afr[(T) & 1][0]);                                                     \
         if ((T) < 8) {             /* the next tap reads the SAME halo buffer at shifted rows: fetch it now */    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
                     afr[((T) + 1) & 1][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[((T) + 1) % 9][i] ^ (ks << 6))); \
         }                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                           \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
-                halo_mma(acc[i][j], bfr[1][j], afr[(T) & 1][1][i]);                                              \
+        halo_mma_tile<MI, NI>(acc, bfr[1], afr[(T) & 1][1]);                                                     \
         if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
     Frag afr[2][2][MI];                    // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
     MDM_T(const unsigned long long tstart = stamp_now();)
-    const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
     for (int cs = 0; cs < NCS; ++cs) {
         MDM_HALO_TAP(0) MDM_HALO_TAP(1) MDM_HALO_TAP(2) MDM_HALO_TAP(3) MDM_HALO_TAP(4)
         MDM_HALO_TAP(5) MDM_HALO_TAP(6) MDM_HALO_TAP(7) MDM_HALO_TAP(8)
@@ -2586,6 +2597,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, 2, 64, float>(d, s) : launch_halo<256, 6, 2, 64, float>(d, s);
         else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float>(d, s)
                                                                                          : launch_halo<128, 6, 3, 64, float>(d, s);
+        else if ((int64_t)(d.M / 64) * (d.N / 64) < kBigMinTiles && d.N % 32 == 0)       // 4x4 maps: 32-channel tiles, twice the workgroups
+            rc = npw <= 2 ? launch_halo<64, 2, 3, 32, float>(d, s) : launch_halo<64, 3, 3, 32, float>(d, s);
         else rc = npw <= 2 ? launch_halo<64, 2, 3, 64, float>(d, s) : launch_halo<64, 3, 3, 64, float>(d, s);
     } else if (d.dtype == MDM_F32) {
         // exact-fp32 MFMA kernel; 128 x 128 tiles when that still gives about one workgroup per CU
