@@ -451,7 +451,7 @@ def main():
         # HBM bytes per launch of this kernel family from PMC counters: collected out of band by
         # scripts/pmc_traffic.sh (rocprofv3 cannot run inside the timed process) and committed under profiles/
         traffic = mfma_busy = pmc_src = None
-        for fn in ("r02_pmc.json", "r01_pmc_traffic.json"):
+        for fn in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:
                     pj = json.load(fh)

@@ -158,16 +158,16 @@ int mdm_wgrad_group_destroy(void* handle);
 /* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)
  * x = concat(src0[C0], src1[C1]) along channels, NHWC, P = H*W pixels per image.
- * stats: [N][G][2] fp32 (mean, rstd).  One kernel per call; with `ws` (fp32 scratch of >= N*32*G*2 floats, may
- * be NULL) maps too large for one workgroup per (image, channel block) to pull HBM bandwidth are cut into pixel
- * chunks: a statistics launch (partials in ws, fixed summation order) and an apply launch.
+ * stats: [N][G][2] fp32 (mean, rstd).  One kernel per call, every sum in a fixed order (no float atomics); `ws` is
+ * not used by the forward (may be NULL).
  * ------------------------------------------------------------------------- */
 int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void* src1, int C1,
                       int N, int P, int G, float eps, const float* gamma, const float* beta,
                       int silu, void* y, float* stats, float* ws, void* stream);
 /* dx -> dst0/dst1 (channel split like the sources), acc flags add into them;
- * dgamma/dbeta are ACCUMULATED (one fp32 atomic per channel per image).  `ws` (may be NULL): fp32 scratch of
- * >= N*32*G*2 floats; with it large maps are cut into pixel chunks (statistics launch + apply launch). */
+ * dgamma/dbeta are ACCUMULATED: bf16, one fp32 atomic per channel per image; fp32 (dtype MDM_F32), NO atomics -- per-image partial
+ * sums go to `ws` (REQUIRED there, >= 3*N*C floats) and a second launch adds them in image order, so the fp32 path gives the same bits
+ * on every run.  (bf16: `ws` may be NULL.) */
 int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int C1,
                       int N, int P, int G, const float* gamma, const float* beta, int silu,
                       const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,

@@ -2,7 +2,7 @@
 # kernel-trace stats of the fp32 reverse sampler (20 steps, sample_num 100)
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/prof_samp; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --sampler-steps 20 > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --sampler-steps 50 > $OUT/bench.log 2>&1
 cd $R
 cp $(ls -t $OUT/run/*/*kernel_stats.csv | head -1) $OUT/stats.csv
 python3 - <<'PY'
