@@ -58,6 +58,21 @@ gb = [torch.empty_like(G) for _ in range(world)]
 dist.all_gather(gb, G)
 assert torch.equal(gb[0], gb[1])
 assert float(G.abs().max()) > 0
+# ---- gradient accumulation under data parallelism: micro-steps add to Gacc locally, the syncing step exchanges ONCE and updates
+step2 = TrainStep(model, S, a, opt, ema, mean_shift=True, comm=GradComm(bucket_bytes=256 << 10), grad_accum=2)
+P1 = model.store.P.clone()
+t_before = opt.t
+step2.run_device(x0, used, sync=False)
+torch.cuda.synchronize()
+assert torch.equal(model.store.P, P1) and opt.t == t_before, "a non-syncing micro-step must not touch the weights"
+assert float(step2.Gacc.abs().max()) > 0
+step2.run_device(x0, used, sync=True)
+torch.cuda.synchronize()
+assert opt.t == t_before + 1 and float((model.store.P - P1).abs().max()) > 0 and float(step2.Gacc.abs().max()) == 0
+P = keep(model.store.P)
+both = [torch.empty_like(P) for _ in range(world)]
+dist.all_gather(both, P)
+assert torch.equal(both[0], both[1]), "replicas diverged under gradient accumulation"
 if rank == 0:
     print("DPGPU_OK", len(comm.buckets), losses)
 dist.barrier()

@@ -423,6 +423,29 @@ def test_groupnorm_fwd_bwd(dt, C0, C1, HW, silu):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_shift_leaves_pad_channels_alone_and_zero_pad_channels_clears_them(dt):
+    """`mdm_shift` writes only the C real channels of the NHWC network input; a caller whose buffer did not come from a
+    zeroing allocator runs `mdm_zero_pad_channels` once (include/mdm_hip.h).  Contract check on a NaN-filled buffer."""
+    from mdm import _lib
+    from mdm._lib import call, ptr, stream
+    dev = _dev()
+    N, C, H, W, Cp = 3, 3, 8, 8, 8
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    x_t = torch.rand(N, C, H, W, device=dev) * 2 - 1
+    buf = torch.full((N, H, W, Cp), float("nan"), device=dev, dtype=tdt)
+    s_out = torch.empty_like(x_t); x_in = torch.empty_like(x_t)
+    call("mdm_shift", ptr(x_t), None, None, None, 2, 0, 0.0, 0, N, C, H, W, ptr(s_out), ptr(x_in), DT[dt], ptr(buf), Cp, stream())
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(buf[..., C:].float()).all()), "mdm_shift must not touch the pad channels"
+    assert torch.equal(buf[..., :C].float().cpu(), x_t.permute(0, 2, 3, 1).to(tdt).float().cpu())          # kind 0: x_in = x_t
+    call("mdm_zero_pad_channels", DT[dt], ptr(buf), N * H * W, C, Cp, stream())
+    torch.cuda.synchronize()
+    assert float(buf[..., C:].float().abs().sum()) == 0.0 and torch.equal(buf[..., :C].float().cpu(), x_t.permute(0, 2, 3, 1).to(tdt).float().cpu())
+    with pytest.raises(RuntimeError, match="zero_pad_channels"):
+        call("mdm_zero_pad_channels", DT[dt], ptr(buf), N * H * W, C, 7, stream())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_softmax_colsum_pool_layout_temb(dt):
     from mdm import ops
     dev = _dev()
