@@ -2230,6 +2230,109 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     conv_halo_body<BM, NPW, BN, NSB, TG, T>(d, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ----------------------------------------------------------------------------
+// The two ENDS of the U-Net (unet6.py:403-404, 505): 3 -> 128 channels in, 128 -> 3 out, with the 3 padded to 8 -- one 16-byte chunk
+// per pixel.  Through the general kernels these ran ~20 us each for 0.6 GFLOP (k-slabs that are not 64-aligned fall back to the
+// register-staged kernel: two 64-deep slabs of per-element gather arithmetic and an 8-byte scattered epilogue).  They are memory-bound
+// streaming problems, and an MFMA fragment of 8 consecutive k IS one tap's 8 channels of one pixel:
+//   conv_thin_k (8 input channels: the first convolution, and the data gradient of the last through the transposed shadow): the reduction
+//     is 9 taps x 8 = 72 -> three k-steps of 4 taps (3 of 12 zero); a lane loads its tap's pixel chunk STRAIGHT from global memory into the
+//     A fragment (no LDS), the filter fragments (3 x N/16, from an 18-KB array) stay in registers while the wave walks its 16-pixel tiles;
+//   conv_thin_n (8 output channels: the last convolution): N padded to one 16-wide MFMA column block, the 9 x C0/32 filter fragments in
+//     LDS (row pitch + 16 B against bank conflicts), pixel fragments straight from global memory (the 3x3 reuse is the L1 / L2's).
+// Same operand order as everywhere: acc holds D[m = lane & 15][n = 4 (lane >> 4) + reg].
+// ----------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(256) void conv_thin_k_kernel(mdm_gemm_desc d) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, r = lane & 15;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B);
+    const bf16_t* S = reinterpret_cast<const bf16_t*>(d.src0);
+    bf16x8 bf[3][NJ];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+        const int tap = 4 * s2 + g;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = j * 16 + r;
+            bf[s2][j] = (tap < 9 && n < d.N) ? *reinterpret_cast<const bf16x8*>(B + (int64_t)tap * d.wtap + (int64_t)n * d.ldb) : zero8;
+        }
+    }
+    const int ntile = (d.M + 15) >> 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+        const int m = tile * 16 + r;
+        const RowPix rp = decode_row(d, m < d.M ? m : 0);
+        bf16x8 af[3];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            const int tap = 4 * s2 + g, ty = tap / 3, tx = tap - ty * 3;
+            const int spix = (tap < 9 && m < d.M) ? gather_pix(d, rp, ty, tx) : -1;
+            af[s2] = spix >= 0 ? *reinterpret_cast<const bf16x8*>(S + (int64_t)spix * d.ld0) : zero8;
+        }
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s2][j], af[s2], acc[j], 0, 0, 0);
+        if (m < d.M) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = j * 16 + 4 * g;
+                if (n >= d.N) continue;
+                float4 v = make_float4(acc[j][0] * d.alpha, acc[j][1] * d.alpha, acc[j][2] * d.alpha, acc[j][3] * d.alpha);
+                if (d.bias) { const float4 b = *reinterpret_cast<const float4*>(d.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                bf16_t* q = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
+                if (d.acc0) { const float4 o = load4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                store4(q, v);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_thin_n_kernel(mdm_gemm_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];               // [9][16][C0] bf16, row pitch C0 * 2 + 16 bytes
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, r = lane & 15;
+    const int C0 = d.C0, pitch = C0 * 2 + 16, KS = C0 >> 5;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B);
+    const bf16_t* S = reinterpret_cast<const bf16_t*>(d.src0);
+    for (int i = t; i < 9 * 16 * (C0 >> 3); i += 256) {                      // 16-byte pieces; rows >= N are zero
+        const int c8 = i % (C0 >> 3), row = (i / (C0 >> 3)) & 15, tap = i / ((C0 >> 3) * 16);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < d.N) v = *reinterpret_cast<const uint4*>(B + (int64_t)tap * d.wtap + (int64_t)row * d.ldb + c8 * 8);
+        *reinterpret_cast<uint4*>(wsm + (tap * 16 + row) * pitch + c8 * 16) = v;
+    }
+    __syncthreads();
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntile = (d.M + 15) >> 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+        const int m = tile * 16 + r;
+        const RowPix rp = decode_row(d, m < d.M ? m : 0);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const int spix = m < d.M ? gather_pix(d, rp, ty, tx) : -1;
+            const bf16_t* px = S + (int64_t)(spix < 0 ? 0 : spix) * d.ld0 + 8 * g;
+            const char* wrow = wsm + (tap * 16 + r) * pitch + 16 * g;
+            for (int s2 = 0; s2 < KS; ++s2) {
+                const bf16x8 a = spix >= 0 ? *reinterpret_cast<const bf16x8*>(px + 32 * s2) : zero8;
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wrow + 64 * s2);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
+            }
+        }
+        const int n = 4 * g;
+        if (m < d.M && n < d.N) {
+            float4 v = make_float4(acc[0] * d.alpha, acc[1] * d.alpha, acc[2] * d.alpha, acc[3] * d.alpha);
+            if (d.bias) { const float4 b = *reinterpret_cast<const float4*>(d.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            bf16_t* q = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
+            if (d.acc0) { const float4 o = load4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            store4(q, v);
+        }
+    }
+}
+
 // TWO independent convolutions in one launch (mdm_gemm_pair): workgroups [0, na) run the 3x3 halo convolution `a`, the rest
 // the 1x1 convolution `b` (conv_lin2).  The pairs are the ResidualBlock's conv1 next to its skip projection in the forward
 // (both only need the block input / its norm) and conv2's data gradient next to the skip projection's in the backward (both
@@ -2420,6 +2523,18 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
     return 0;
 }
 
+// 0: no; 1: conv_thin_k (Cin padded = 8); 2: conv_thin_n (Cout padded = 8).  3x3 stride-1 "same" bf16 convolutions, layout 0 (forward, or
+// the data gradient through the transposed shadow), one source, plain epilogue (scale, bias, accumulate)
+static int thin_conv(const mdm_gemm_desc& d) {
+    if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 && d.pad_t == 1 &&
+          d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW && d.C1 == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.rowvec && !d.resid &&
+          d.splitk <= 1 && !d.gnb_x && !d.gnf_out && d.N % 4 == 0 && d.ldd0 % 4 == 0))
+        return 0;
+    if (d.C0 == 8 && d.Ck == 8 && d.ldb == 8 && d.ld0 % 8 == 0 && d.N <= 128 && d.N >= 16) return 1;
+    if (d.N == 8 && d.C0 % 32 == 0 && d.C0 <= 512 && d.Ck == d.C0 && d.ldb % 8 == 0 && d.ld0 % 8 == 0) return 2;
+    return 0;
+}
+
 static bool ring_eligible(const mdm_gemm_desc& d) {
     if (d.dtype != MDM_BF16) return false;
     if (d.layout == 2) return true;
@@ -2605,6 +2720,26 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         const bool big32 = d.M >= 128 && d.N >= 128 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * grid.z >= kBigMinTiles;
         rc = big32 ? launch_f32_mfma<128, 128>(d, dim3((unsigned)((int64_t)cdiv(d.M, 128) * cdiv(d.N, 128)), 1, grid.z), s)
                    : launch_f32_mfma<64, 64>(d, grid, s);
+    } else if (const int thin = thin_conv(d)) {
+        // the two ends of the U-Net: 8 padded input channels (thin == 1) or 8 padded output channels (thin == 2)
+        const int ntile = cdiv(d.M, 16);
+        const unsigned nb = (unsigned)std::min(cdiv(ntile, 4), 1024);
+        if (thin == 1) {
+            switch (cdiv(d.N, 16)) {
+                case 1: hipLaunchKernelGGL((conv_thin_k_kernel<1>), dim3(nb), dim3(256), 0, s, d); break;
+                case 2: hipLaunchKernelGGL((conv_thin_k_kernel<2>), dim3(nb), dim3(256), 0, s, d); break;
+                case 3: case 4: hipLaunchKernelGGL((conv_thin_k_kernel<4>), dim3(nb), dim3(256), 0, s, d); break;
+                default: hipLaunchKernelGGL((conv_thin_k_kernel<8>), dim3(nb), dim3(256), 0, s, d); break;
+            }
+        } else {
+            const int bytes = 9 * 16 * (d.C0 * 2 + 16);
+            static int configured = 0;
+            if (configured < bytes) {
+                MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_thin_n_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+                configured = bytes;
+            }
+            hipLaunchKernelGGL(conv_thin_n_kernel, dim3(nb), dim3(256), bytes, s, d);
+        }
     } else if (const ConvVar cv = conv_variant(d, r, grid.z)) {
         const dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
         switch (cv) {

@@ -56,6 +56,9 @@ CONV_CASES = [
     (4, 8, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample, 16x16 virtual map: linear-gather weight gradient
     (32, 8, 64, 0, 128, 3, 1, (1, 1, 1, 1), 1),     # folded upsample, enough tiles for the halo kernel (forward)
     (8, 4, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample onto an 8x8 map: whole-image halo tiles
+    (4, 32, 8, 0, 128, 3, 1, (1, 1, 1, 1), 0),      # the first convolution (3 -> 8 padded input channels): conv_thin_k; its "dgrad_t" is conv_thin_n
+    (3, 16, 128, 0, 8, 3, 1, (1, 1, 1, 1), 0),      # the last convolution (8 padded output channels): conv_thin_n; its dgrad_t is conv_thin_k
+    (2, 8, 8, 0, 48, 3, 1, (1, 1, 1, 1), 0),        # conv_thin_k with a partial last 16-column block and a ragged pixel tile count
 ]
 
 
