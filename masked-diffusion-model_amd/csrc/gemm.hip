@@ -494,6 +494,65 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
 }
 
 // ----------------------------------------------------------------------------
+// fp32 weight gradient of a linear layer whose reduction is the BATCH (layout 2, K <= 128 rows): D[m][n] (=|+=) alpha sum_k A[k][m] B[k][n],
+// dbias[m] += sum_k A[k][m].  The time-embedding path's three weight gradients (unet6.py:395-399, 350: [4992|512|512] x [512|512|128] from 32
+// rows) took 16 / 11 / 11 us on the 64x64x32 MFMA tiles -- a 32-deep reduction never fills that pipeline; they are 10 / 1 / 0.25 MB of
+// output to write.  Here: both operand panels (K x 64 each) parked in LDS once, 4 x 4 outputs per thread, k-ordered fmaf chain (fixed
+// order, bit-reproducible), 16-byte stores.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tn_skinny_f32_kernel(mdm_gemm_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];             // As[K][64] | Bs[K][64]
+    const int t = threadIdx.x, K = d.K;
+    const int tiles_n = (d.N + 63) >> 6;
+    const int m0 = (blockIdx.x / tiles_n) * 64, n0 = (blockIdx.x % tiles_n) * 64;
+    const float* A = reinterpret_cast<const float*>(d.A);
+    const float* B = reinterpret_cast<const float*>(d.B);
+    float* As = tsm;
+    float* Bs = tsm + K * 64;
+    for (int i = t; i < K * 16; i += 256) {
+        const int k = i >> 4, c4 = (i & 15) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (m0 + c4 < d.M) a = *reinterpret_cast<const float4*>(A + (int64_t)k * d.lda + m0 + c4);
+        if (n0 + c4 < d.N) b = *reinterpret_cast<const float4*>(B + (int64_t)k * d.ldb + n0 + c4);
+        *reinterpret_cast<float4*>(As + k * 64 + c4) = a;
+        *reinterpret_cast<float4*>(Bs + k * 64 + c4) = b;
+    }
+    __syncthreads();
+    const int ty = t >> 4, tx = t & 15;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float4 a = *reinterpret_cast<const float4*>(As + k * 64 + 4 * ty);
+        const float4 b = *reinterpret_cast<const float4*>(Bs + k * 64 + 4 * tx);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    const int n = n0 + 4 * tx;
+    if (n < d.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 4 * ty + i;
+            if (m >= d.M) continue;
+            float4 v = make_float4(acc[i][0] * d.alpha, acc[i][1] * d.alpha, acc[i][2] * d.alpha, acc[i][3] * d.alpha);
+            float* q = reinterpret_cast<float*>(d.D0) + (int64_t)m * d.ldd0 + n;
+            if (d.acc0) { const float4 o = *reinterpret_cast<const float4*>(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(q) = v;
+        }
+    }
+    if (d.dbias && n0 == 0 && t < 64 && m0 + t < d.M) {          // one writer per element, k order
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += As[k * 64 + t];
+        d.dbias[m0 + t] += sum;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // Skinny fp32 linear layer D[m][n] = alpha * sum_k A[m][k] B[n][k] + bias[n] with M <= 32 rows (the batch):
 // the time-embedding MLP and the per-block projections (unet6.py:395-399, 350).  A 64x64-tiled kernel gives
 // 8 workgroups for a [32,512]x[512,512] layer, each pulling 128 KB of weights alone (36 us, and three such
@@ -2238,8 +2297,9 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 //   conv_thin_k (8 input channels: the first convolution, and the data gradient of the last through the transposed shadow): the reduction
 //     is 9 taps x 8 = 72 -> three k-steps of 4 taps (3 of 12 zero); a lane loads its tap's pixel chunk STRAIGHT from global memory into the
 //     A fragment (no LDS), the filter fragments (3 x N/16, from an 18-KB array) stay in registers while the wave walks its 16-pixel tiles;
-//   conv_thin_n (8 output channels: the last convolution): N padded to one 16-wide MFMA column block, the 9 x C0/32 filter fragments in
-//     LDS (row pitch + 16 B against bank conflicts), pixel fragments straight from global memory (the 3x3 reuse is the L1 / L2's).
+//   (The mirror image for the LAST convolution -- 8 output channels, 1152-deep reduction, pixel fragments straight from global memory,
+//    filter fragments in LDS -- was written and measured at 18.8 us against the general kernel's 16.6: without a halo in LDS the 3x3
+//    re-reads of a 128-channel pixel go to L2 nine times.  Not kept.)
 // Same operand order as everywhere: acc holds D[m = lane & 15][n = 4 (lane >> 4) + reg].
 // ----------------------------------------------------------------------------
 template <int NJ>
@@ -2287,48 +2347,6 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(mdm_gemm_desc d) {
                 if (d.acc0) { const float4 o = load4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                 store4(q, v);
             }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void conv_thin_n_kernel(mdm_gemm_desc d) {
-    extern __shared__ __attribute__((aligned(16))) char wsm[];               // [9][16][C0] bf16, row pitch C0 * 2 + 16 bytes
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, r = lane & 15;
-    const int C0 = d.C0, pitch = C0 * 2 + 16, KS = C0 >> 5;
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(d.B);
-    const bf16_t* S = reinterpret_cast<const bf16_t*>(d.src0);
-    for (int i = t; i < 9 * 16 * (C0 >> 3); i += 256) {                      // 16-byte pieces; rows >= N are zero
-        const int c8 = i % (C0 >> 3), row = (i / (C0 >> 3)) & 15, tap = i / ((C0 >> 3) * 16);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < d.N) v = *reinterpret_cast<const uint4*>(B + (int64_t)tap * d.wtap + (int64_t)row * d.ldb + c8 * 8);
-        *reinterpret_cast<uint4*>(wsm + (tap * 16 + row) * pitch + c8 * 16) = v;
-    }
-    __syncthreads();
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int ntile = (d.M + 15) >> 4;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
-        const int m = tile * 16 + r;
-        const RowPix rp = decode_row(d, m < d.M ? m : 0);
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ty = tap / 3, tx = tap - ty * 3;
-            const int spix = m < d.M ? gather_pix(d, rp, ty, tx) : -1;
-            const bf16_t* px = S + (int64_t)(spix < 0 ? 0 : spix) * d.ld0 + 8 * g;
-            const char* wrow = wsm + (tap * 16 + r) * pitch + 16 * g;
-            for (int s2 = 0; s2 < KS; ++s2) {
-                const bf16x8 a = spix >= 0 ? *reinterpret_cast<const bf16x8*>(px + 32 * s2) : zero8;
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wrow + 64 * s2);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
-            }
-        }
-        const int n = 4 * g;
-        if (m < d.M && n < d.N) {
-            float4 v = make_float4(acc[0] * d.alpha, acc[1] * d.alpha, acc[2] * d.alpha, acc[3] * d.alpha);
-            if (d.bias) { const float4 b = *reinterpret_cast<const float4*>(d.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-            bf16_t* q = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
-            if (d.acc0) { const float4 o = load4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            store4(q, v);
         }
     }
 }
@@ -2523,16 +2541,13 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
     return 0;
 }
 
-// 0: no; 1: conv_thin_k (Cin padded = 8); 2: conv_thin_n (Cout padded = 8).  3x3 stride-1 "same" bf16 convolutions, layout 0 (forward, or
-// the data gradient through the transposed shadow), one source, plain epilogue (scale, bias, accumulate)
-static int thin_conv(const mdm_gemm_desc& d) {
-    if (!(d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 && d.pad_t == 1 &&
-          d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW && d.C1 == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.rowvec && !d.resid &&
-          d.splitk <= 1 && !d.gnb_x && !d.gnf_out && d.N % 4 == 0 && d.ldd0 % 4 == 0))
-        return 0;
-    if (d.C0 == 8 && d.Ck == 8 && d.ldb == 8 && d.ld0 % 8 == 0 && d.N <= 128 && d.N >= 16) return 1;
-    if (d.N == 8 && d.C0 % 32 == 0 && d.C0 <= 512 && d.Ck == d.C0 && d.ldb % 8 == 0 && d.ld0 % 8 == 0) return 2;
-    return 0;
+// conv_thin_k: 3x3 stride-1 "same" bf16 convolution with 8 (padded) input channels, layout 0 (forward, or the data gradient of an
+// 8-output-channel convolution through the transposed shadow), one source, plain epilogue (scale, bias, accumulate)
+static bool thin_conv(const mdm_gemm_desc& d) {
+    return d.dtype == MDM_BF16 && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 && d.pad_t == 1 &&
+           d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW && d.C1 == 0 && d.N0 == d.N && !d.D1 && !d.out_f32 && !d.rowvec && !d.resid &&
+           d.splitk <= 1 && !d.gnb_x && !d.gnf_out && d.N % 4 == 0 && d.ldd0 % 4 == 0 &&
+           d.C0 == 8 && d.Ck == 8 && d.ldb == 8 && d.ld0 % 8 == 0 && d.N <= 128 && d.N >= 16;
 }
 
 static bool ring_eligible(const mdm_gemm_desc& d) {
@@ -2706,6 +2721,16 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             configured = true;
         }
         hipLaunchKernelGGL(linear_skinny_f32_kernel, dim3((unsigned)cdiv(d.N, 16)), dim3(256), bytes, s, d);
+    } else if (d.dtype == MDM_F32 && d.layout == 2 && !d.conv && d.batch == 1 && d.K <= 128 && d.splitk <= 1 && d.N0 == d.N && !d.D1 &&
+               d.M % 4 == 0 && d.N % 4 == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.ldd0 % 4 == 0 && !d.bias && !d.rowvec && !d.resid) {
+        // weight gradient of a linear layer over a batch-sized reduction (the time-embedding path)
+        const int bytes = d.K * 128 * 4;
+        static int configured = 0;
+        if (configured < bytes) {
+            MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_skinny_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            configured = bytes;
+        }
+        hipLaunchKernelGGL(tn_skinny_f32_kernel, dim3((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 64))), dim3(256), bytes, s, d);
     } else if (const int hb32 = halo_tile_f32(d)) {
         // exact-fp32 3x3 convolutions on the halo kernel (forward, folded upsample, transposed shadow): MFMA-bound
         const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
@@ -2720,25 +2745,14 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         const bool big32 = d.M >= 128 && d.N >= 128 && (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * grid.z >= kBigMinTiles;
         rc = big32 ? launch_f32_mfma<128, 128>(d, dim3((unsigned)((int64_t)cdiv(d.M, 128) * cdiv(d.N, 128)), 1, grid.z), s)
                    : launch_f32_mfma<64, 64>(d, grid, s);
-    } else if (const int thin = thin_conv(d)) {
-        // the two ends of the U-Net: 8 padded input channels (thin == 1) or 8 padded output channels (thin == 2)
-        const int ntile = cdiv(d.M, 16);
-        const unsigned nb = (unsigned)std::min(cdiv(ntile, 4), 1024);
-        if (thin == 1) {
-            switch (cdiv(d.N, 16)) {
-                case 1: hipLaunchKernelGGL((conv_thin_k_kernel<1>), dim3(nb), dim3(256), 0, s, d); break;
-                case 2: hipLaunchKernelGGL((conv_thin_k_kernel<2>), dim3(nb), dim3(256), 0, s, d); break;
-                case 3: case 4: hipLaunchKernelGGL((conv_thin_k_kernel<4>), dim3(nb), dim3(256), 0, s, d); break;
-                default: hipLaunchKernelGGL((conv_thin_k_kernel<8>), dim3(nb), dim3(256), 0, s, d); break;
-            }
-        } else {
-            const int bytes = 9 * 16 * (d.C0 * 2 + 16);
-            static int configured = 0;
-            if (configured < bytes) {
-                MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_thin_n_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-                configured = bytes;
-            }
-            hipLaunchKernelGGL(conv_thin_n_kernel, dim3(nb), dim3(256), bytes, s, d);
+    } else if (thin_conv(d)) {
+        // the 8-channel ends of the U-Net: the first convolution and the data gradient of the last
+        const unsigned nb = (unsigned)std::min(cdiv(cdiv(d.M, 16), 4), 1024);
+        switch (cdiv(d.N, 16)) {
+            case 1: hipLaunchKernelGGL((conv_thin_k_kernel<1>), dim3(nb), dim3(256), 0, s, d); break;
+            case 2: hipLaunchKernelGGL((conv_thin_k_kernel<2>), dim3(nb), dim3(256), 0, s, d); break;
+            case 3: case 4: hipLaunchKernelGGL((conv_thin_k_kernel<4>), dim3(nb), dim3(256), 0, s, d); break;
+            default: hipLaunchKernelGGL((conv_thin_k_kernel<8>), dim3(nb), dim3(256), 0, s, d); break;
         }
     } else if (const ConvVar cv = conv_variant(d, r, grid.z)) {
         const dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
