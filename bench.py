@@ -365,8 +365,9 @@ def main():
     if os.environ.get("MDM_FORCE_DEVICE") is not None:
         local = int(os.environ["MDM_FORCE_DEVICE"])
     torch.cuda.set_device(local)
-    if world > 1:
-        init_from_env(os.environ.get("MDM_DIST_BACKEND", "nccl"))
+    rehearse = world == 1 and os.environ.get("MDM_REHEARSE_COMM") == "1"      # one rank, RCCL collectives issued anyway (one-GPU box)
+    if world > 1 or rehearse:
+        init_from_env(os.environ.get("MDM_DIST_BACKEND", "nccl"), single=rehearse)
     dev = torch.device("cuda", local)
     dt = mdm.BF16 if opt_.dtype == "bf16" else mdm.F32
     N = opt_.batch
@@ -384,7 +385,7 @@ def main():
     sched = mdm.Scheduler(args, device=dev)
     sched.update_ddpm_num_steps(1000)
     used = sched.get_timesteps_epoch(0, 1)
-    comm = GradComm(wire=opt_.grad_wire) if world > 1 else None
+    comm = GradComm(wire=opt_.grad_wire, always_exchange=rehearse) if (world > 1 or rehearse) else None
     step = TrainStep(model, sched, args, optim, ema, mean_shift=True, comm=comm)
     g = torch.Generator().manual_seed(100 + rank)
     step.x0.copy_(torch.rand(N, 3, 32, 32, generator=g) * 2 - 1)          # synthetic batch, resident in HBM
@@ -392,7 +393,7 @@ def main():
     log(f"model built: {model.num_parameters()} params, {len(model.forward_plan.calls)} fwd / {len(model.backward_plan.calls)} bwd launches")
 
     def barrier():
-        if world > 1:
+        if world > 1 or rehearse:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -408,7 +409,7 @@ def main():
         step.run_device(None, used)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or rehearse:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
@@ -575,7 +576,7 @@ def main():
         if extras:
             out["extras"] = extras
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rehearse:
         torch.distributed.destroy_process_group()
 
 

@@ -18,13 +18,17 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's env (RANK/WORLD_SIZE/MASTER_*)."""
+def init_from_env(backend=None, single=False):
+    """Initialise the default process group from torchrun's env (RANK/WORLD_SIZE/MASTER_*).  `single`: also for a world of
+    one (a rehearsal of the RCCL path on a one-GPU box; a one-rank job needs no group otherwise)."""
     import os
     if dist.is_initialized():
         return
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not single:
         return
+    if single:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl" and os.environ.get("MDM_FORCE_DEVICE") is None:
@@ -39,10 +43,13 @@ class GradComm:
     price of one rounding of every gradient element before the sum (replicas stay bit-identical: every rank widens the
     same reduced values).  Default fp32: at cfg2 the exchange hides behind the backward except for the last bucket."""
 
-    def __init__(self, group=None, bucket_bytes=32 << 20, tail_bytes=4 << 20, wire="f32"):
+    def __init__(self, group=None, bucket_bytes=32 << 20, tail_bytes=4 << 20, wire="f32", always_exchange=False):
         assert wire in ("f32", "bf16"), wire
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a world of one has nothing to exchange; `always_exchange` issues the collectives anyway (the sum over one rank is
+        # the identity) so that a one-GPU box can run the RCCL code path: tests/test_dp_gpu.py, bench.py MDM_REHEARSE_COMM=1
+        self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_bytes = bucket_bytes
         self.tail_bytes = min(tail_bytes, bucket_bytes)
@@ -86,7 +93,7 @@ class GradComm:
 
     # ---- exchange ---------------------------------------------------------------------------
     def reduce_bucket(self, i, G):
-        if self.world == 1:
+        if not self.exchange:
             return
         lo, hi = self.buckets[i]
         if self.wire == "bf16":
@@ -108,5 +115,5 @@ class GradComm:
         self._handles = []
 
     def allreduce_all(self, G):
-        if self.world > 1:
+        if self.exchange:
             dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group)

@@ -97,6 +97,69 @@ def test_two_ranks_one_gpu_gloo(tmp_path, mode):
     assert "DPGPU_OK" in outs[0]
 
 
+_WORKER_RCCL1 = r'''
+import os, sys
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "masked-diffusion-model_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+import mdm
+from mdm.dist import GradComm, init_from_env
+from mdm.train_step import TrainStep
+from golden.make_golden import TINY, base_args
+from oracle.unet_ref import random_params
+mode, wire = sys.argv[2], sys.argv[3]
+torch.cuda.set_device(0)
+init_from_env("nccl", single=True)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+
+def run(comm):
+    a = base_args(data_size=16, ddpm_schedule="linear", ddpm_num_steps=50, shift_type="noise_with_perturbation",
+                  rng_mode="device", use_ema=True, seed=100, use_graph=(mode == "graph"))
+    model = mdm.UNet(TINY, N=4, H=16, W=16, dtype=mdm.F32, params=random_params(TINY), use_graph=a.use_graph, wgrad_group_bytes=200 << 10)
+    opt = mdm.AdamW(model, lr=1e-3); ema = mdm.EMA(model)
+    S = mdm.Scheduler(a); S.update_ddpm_num_steps(50)
+    used = S.get_timesteps_epoch(0, 1)
+    step = TrainStep(model, S, a, opt, ema, mean_shift=True, comm=comm)
+    x0 = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    losses = [float(step.run_device(x0, used)) for _ in range(4)]
+    torch.cuda.synchronize()
+    return model.store.P.clone(), model.store.G.clone(), losses
+
+comm = GradComm(bucket_bytes=256 << 10, wire=wire, always_exchange=True)
+assert comm.exchange and comm.world == 1
+P1, G1, l1 = run(comm)
+assert len(comm.buckets) >= 3, comm.buckets
+P0, G0, l0 = run(None)                      # the whole-graph step without any exchange
+if wire == "f32":                           # a sum over one rank is the identity: bit-equal weights after 4 steps (fp32 path, fixed-order)
+    assert torch.equal(P1, P0) and torch.equal(G1, G0) and l1 == l0, (float((P1 - P0).abs().max()), l1, l0)
+else:                                       # one bf16 rounding of every gradient element on the wire
+    rel = float((G1 - G0).norm() / G0.norm())
+    assert 0 < rel < 1e-2, rel
+# the collectives RCCL would see in a real job, on the same views of the flat buffer
+t = G1[: 1 << 16].clone(); dist.all_reduce(t); torch.cuda.synchronize(); assert torch.equal(t, G1[: 1 << 16])
+dist.barrier()
+print("RCCL1_OK", len(comm.buckets), l1)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode,wire", [("graph", "f32"), ("eager", "f32"), ("graph", "bf16")])
+def test_one_rank_rccl_cut_step(tmp_path, mode, wire):
+    """The RCCL ("nccl") backend itself on the one GPU there is: a world of one, the collectives issued anyway
+    (`GradComm(always_exchange=True)`), so the cut step graph, the async all-reduce per bucket on RCCL's stream and the stream-level
+    waits all run through the library a multi-GPU job uses.  With a sum over one rank being the identity the fp32 step must
+    equal the whole-graph single-GPU step bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER_RCCL1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT, mode, wire], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def _device_count():
     import torch
     return torch.cuda.device_count()
