@@ -1507,7 +1507,14 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
 
 #ifdef MDM_STAMP
 // debug build only (make EXTRA=-DMDM_STAMP): cycles per phase of the slab loop, summed over waves
-__device__ unsigned long long g_stamp_buf[4096 * 32];     // one 32-entry record per wave, plain stores
+#define MDM_STAMP_RECS 32768
+__device__ unsigned long long g_stamp_buf[MDM_STAMP_RECS * 32];     // one 32-entry record per wave (weight gradients: per workgroup), plain stores
+__device__ __forceinline__ unsigned long long stamp_hw_id() {      // which CU this wave runs on: HW_ID (cu / sh / se fields) | XCC_ID << 32
+    unsigned a, b;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(a));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(b));
+    return ((unsigned long long)b << 32) | a;
+}
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -2007,12 +2014,14 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
     }
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
-        const unsigned widx = (unsigned)blockIdx.x * NW + wave;
-        if (widx < 4096) {
+    if (lane == 0 && wave == 0) {          // one record per WORKGROUP (a group launch has thousands of them)
+        const unsigned widx = (unsigned)blockIdx.x;
+        if (widx < MDM_STAMP_RECS) {
             unsigned long long* r = g_stamp_buf + widx * 32;
+            const unsigned long long t_end = stamp_now();
             r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = nk > 0 ? nk : 0; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
-            r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
+            r[8] = tstart - t_entry; r[9] = t_end - t_loop_end; r[10] = t_entry;
+            r[11] = BM; r[12] = d.M; r[13] = d.N; r[14] = d.K; r[15] = stamp_hw_id(); r[16] = t_end; r[17] = d.KH * d.KW; r[18] = d.splitk;
         }
     }
 #endif
@@ -2022,6 +2031,324 @@ __device__ __forceinline__ void wgrad_lin_body(const mdm_gemm_desc& d, int item,
 template <int BM, int BN, int NSTAGE, int NW>
 __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d, int tiles_x) {
     wgrad_lin_body<BM, BN, NSTAGE, NW>(d, (int)blockIdx.x, tiles_x);
+}
+
+// ----------------------------------------------------------------------------
+// wgrad_taps: ALL NINE TAPS of a 3x3 stride-1 weight gradient from one pass over dY and the layer input.
+// wgrad_lin runs every filter tap as its own contraction and every wave reads its MFMA fragments with the transposing
+// ds_read_b64_tr_b16 (both operands are pixel-major in memory, the contraction runs over pixels).  Stamps inside the grouped
+// launch: 2 500 cycles per 64-pixel slab of a 256x128 tile against 1 024 of MFMA -- and the same ~10 cycles per transposing
+// read instruction per CU on every tile shape: the loop is bound by the LDS transposing reads, which the waves of a tile repeat
+// for each other (4x on dY) and the nine taps repeat on the same input pixels.
+// Here a 128 (output channels) x 64 (input channels) tile
+//   * lands dY slabs and input blocks pixel-major by LDS-DMA as before, then transposes each of them ONCE (one transposing
+//     read + one ds_write_b128 per 8 pixels x 16 channels, shared out over the 8 waves) into channel-major arrays At[128][64 px]
+//     and Xt[64][256 px ring]; the fragments of the loop are then plain 16-byte reads (8 consecutive pixels of one channel);
+//   * takes the nine taps from the SAME ring: tap (ty, tx) reads at pixel offset (ty - 1) W + (tx - 1).  The row offset is an
+//     address; the +-1 pixel of tx is made in registers from the centre fragment and its two neighbour dwords (v_alignbit);
+//   * masks what lies outside the image in registers: x neighbours by a lane-constant AND on one register of the fragment (a
+//     fragment is 8 consecutive pixels of one image row, W >= 8), y neighbours by zeroing fragments of the first / last row;
+//   * a folded nearest x2 upsample (unet6.py:472) only changes the address the input DMA reads a (virtual) pixel from.
+// 24 KB of operands per slab for 9.4 MFLOP (per-tap tiles: 48 KB for 4.2), 36 fp32 accumulator tiles (144 registers) per wave.
+// Work item = (tile, range of slabs [k0, k1)): the host cuts the (tile, slab) space of a whole group into one contiguous
+// share per CU (mdm_wgrad_group_create), so a tile that is cut writes its partial sums to a `slot` ([9][128][64] fp32) and
+// tile_parts_reduce_kernel adds the slots; an uncut tile goes straight to the gradient.
+// Requires: 3x3, stride 1, pad 1, OW in {8, 16, 32}, OH a power of two, OH OW >= 64, M % 128 == 0, N % 64 == 0, bf16.
+// ----------------------------------------------------------------------------
+constexpr int TAPS_BM = 128, TAPS_BN = 64, TAPS_SLOT_FLOATS = 9 * TAPS_BM * TAPS_BN;
+constexpr int TAPS_XL = 0, TAPS_XT = 3 * 8192, TAPS_XT_PITCH = 528, TAPS_AL = TAPS_XT + 64 * TAPS_XT_PITCH, TAPS_AT = TAPS_AL + 3 * 16384,
+              TAPS_AT_PITCH = 144, TAPS_LDS_BYTES = TAPS_AT + 2 * TAPS_BM * TAPS_AT_PITCH;
+static_assert(TAPS_LDS_BYTES <= 3 * (256 + 128) * 64 * 2 && 2 * TAPS_BM * TAPS_BN * 4 <= TAPS_LDS_BYTES, "nine-tap LDS map");
+
+__device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+// LDS traffic of the loop through asm: the compiler cannot tell these addresses from the LDS-DMA destinations in flight and
+// would otherwise wait for vmcnt(0) in front of the first read (see ring_frag_cols_issue)
+__device__ __forceinline__ void lds_read16(unsigned addr, v4u_t& v) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void lds_read4(unsigned addr, unsigned& v) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void lds_write16(unsigned addr, const v4u_t& v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void tr_issue_at(unsigned a0, unsigned a1, TrFrag& f) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1) : "memory");
+}
+
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const int tile_i, const int k0, const int k1, float* slot) {
+    constexpr int BM = TAPS_BM, BN = TAPS_BN, NW = 8, MI = 4;
+    extern __shared__ __attribute__((aligned(1024))) char ring[];
+    MDM_T(const unsigned long long t_entry = stamp_now();)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = d.N / BN;
+    const int tile_m = udiv_small(tile_i, tiles_n);
+    const int m0 = tile_m * BM, n0 = (tile_i - tile_m * tiles_n) * BN;
+    const int W = d.OW, H = d.OH, lw = __builtin_ctz(d.OW), lh = __builtin_ctz(d.OH);
+    const int nk = k1 - k0, total_slabs = d.K >> 6;
+    const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
+    const int i16 = lane & 15, g4 = lane >> 4;
+
+    // ---- landing buffers.  dY: [64 pixels][128 channels] per stage, 16 pieces of 4 pixel rows, two per wave (as wgrad_lin)
+    const char* pa[2];
+    const int64_t a_step = (int64_t)64 * d.lda * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kl = (wave * 2 + j) * 4 + (lane >> 4);
+        const int gm = m0 + 8 * ((lane & 15) ^ swz_cols<16>(kl));
+        pa[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.A) + ((int64_t)k0 * 64 + kl) * d.lda + gm);
+    }
+    // input pixels: [64 pixels][64 channels] per block, one piece (8 pixel rows) per wave
+    const int xrow = 8 * wave + (lane >> 3);
+    const int xgn = n0 + 8 * ((lane & 7) ^ swz2(xrow));
+    const bool xs1 = xgn >= d.C0;
+    const int xld = xs1 ? d.ld1 : d.ld0;
+    const bf16_t* const xS = reinterpret_cast<const bf16_t*>(xs1 ? d.src1 : d.src0) + (xs1 ? xgn - d.C0 : xgn);
+    const int ups = d.ups;
+    auto x_src = [&](int blk) -> const char* {                    // where block `blk` (pixels 64 blk ..) comes from
+        if (blk < 0 || blk >= total_slabs || blk > k1) return zlane;
+        const int p = blk * 64 + xrow;
+        int phys = p;
+        if (ups) {
+            const int x = p & (W - 1), y = (p >> lw) & (H - 1), img = p >> (lw + lh);
+            phys = ((img * (H >> 1) + (y >> 1)) << (lw - 1)) + (x >> 1);
+        }
+        return reinterpret_cast<const char*>(xS + (int64_t)phys * xld);
+    };
+    auto stage3 = [](int v) { return v - 3 * (int)(((unsigned)(v + 3000) * 43691u >> 17) - 1000); };      // v mod 3 for v >= -3000
+    auto issue_a = [&](int slab) {                                // dY slab -> landing stage slab mod 3
+        const bool live = slab < k1;
+        char* dst = ring + TAPS_AL + stage3(slab) * 16384;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            lds_dma16(live ? pa[j] : zlane, dst + (wave * 2 + j) * 1024);
+            pa[j] += a_step;
+        }
+    };
+    auto issue_x = [&](int blk) { lds_dma16(x_src(blk), ring + TAPS_XL + stage3(blk) * 8192 + wave * 1024); };
+
+    // ---- transposes: landing (pixel-major) -> At / Xt (channel-major).  X: unit = wave: 16 channels x 32 pixels
+    const int xcg = wave & 3, xks = wave >> 2;
+    unsigned xt_src[2];                                           // the transposing read of this lane inside a landing block
+    {
+        const int col = xcg * 16 + 4 * (i16 & 3), ch = col >> 3, half = (col >> 2) & 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = xks * 32 + 8 * g4 + (i16 >> 2) + 4 * h;
+            xt_src[h] = (unsigned)(q * 128 + ((ch ^ swz2(q)) << 4) + half * 8);
+        }
+    }
+    const unsigned xt_dst = lds0 + TAPS_XT + (unsigned)((xcg * 16 + i16) * TAPS_XT_PITCH);          // + 2 * ((64 blk + 32 ks + 8 g) & 255)
+    auto transpose_x = [&](int blk, TrFrag& f) {
+        const unsigned src = lds0 + TAPS_XL + (unsigned)(stage3(blk) * 8192);
+        tr_issue_at(src + xt_src[0], src + xt_src[1], f);
+    };
+    auto store_x = [&](int blk, const TrFrag& f) {
+        const v4u_t v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+        lds_write16(xt_dst + 2u * (unsigned)((blk * 64 + xks * 32 + 8 * g4) & 255), v);
+    };
+    // dY: 16 units of 16 channels x 32 pixels, two per wave
+    auto transpose_a = [&](int slab, TrFrag (&f)[2]) {
+        const char* src = ring + TAPS_AL + stage3(slab) * 16384;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int u = wave * 2 + j; ring_frag_cols_issue<16>(src, (u & 7) * 16, u >> 3, lane, f[j]); }
+    };
+    auto store_a = [&](int slab, const TrFrag (&f)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = wave * 2 + j;
+            const v4u_t v = {f[j].lo[0], f[j].lo[1], f[j].hi[0], f[j].hi[1]};
+            lds_write16(lds0 + TAPS_AT + (unsigned)((slab & 1) * (BM * TAPS_AT_PITCH) + ((u & 7) * 16 + i16) * TAPS_AT_PITCH + ((u >> 3) * 32 + 8 * g4) * 2), v);
+        }
+    };
+
+    // ---- fragment addresses of the loop (lane constants)
+    const unsigned a_frag = lds0 + TAPS_AT + (unsigned)((wr * 64 + i16) * TAPS_AT_PITCH + 16 * g4);      // + buf, + i * 16 rows, + 64 ks
+    const unsigned b_row = lds0 + TAPS_XT + (unsigned)((wc * 16 + i16) * TAPS_XT_PITCH);                 // + 2 * (pixel & 255)
+    // x masks (lane constants): element 0 of a fragment is pixel x = (32 ks + 8 g) mod W, element 7 is x + 7
+    unsigned mlo[2], mhi[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int x0 = (ks * 32 + 8 * g4) & (W - 1);
+        mlo[ks] = x0 == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;
+        mhi[ks] = x0 + 7 == W - 1 ? 0x0000FFFFu : 0xFFFFFFFFu;
+    }
+
+    f32x4 acc[9][MI][1];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[tp][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient (column sums of dY) on the first input-channel tile of a layer: on the VALU, one fp32 per fragment and lane
+    // (an MFMA against ones would cost 16 more accumulator registers next to the 144 of the taps)
+    const bool do_bias = BIAS && wc == 0;
+    float bsum[BIAS ? MI : 1];
+#pragma unroll
+    for (int i = 0; i < (BIAS ? MI : 1); ++i) bsum[i] = 0.f;
+
+    // ---- prologue: blocks k0-1 .. k0+1 and slab k0 transposed, block k0+2 / slab k0+1 landed, block k0+3 / slab k0+2 in flight
+    issue_x(k0 - 1); issue_x(k0); issue_x(k0 + 1); issue_a(k0);
+    wait_vmcnt<0>();
+    __syncthreads();
+    {
+        TrFrag fx[3], fa[2];
+        transpose_x(k0 - 1, fx[0]); transpose_x(k0, fx[1]); transpose_x(k0 + 1, fx[2]); transpose_a(k0, fa);
+        wait_lgkmcnt<0>();
+        store_x(k0 - 1, fx[0]); store_x(k0, fx[1]); store_x(k0 + 1, fx[2]); store_a(k0, fa);
+        wait_lgkmcnt<0>();              // (asm stores: the compiler's own wait in front of the barrier does not know them)
+    }
+    __syncthreads();                    // (the landing stages of k0-1 .. k0+1 / k0 are read: they may be refilled)
+    issue_x(k0 + 2); issue_a(k0 + 1);
+    issue_x(k0 + 3); issue_a(k0 + 2);
+    MDM_T(const unsigned long long tstart = stamp_now(); unsigned long long tw = 0, tt = 0, tc = 0;)
+    for (int it = 0; it < nk; ++it) {
+        const int s = k0 + it;
+        MDM_T(const unsigned long long q0 = stamp_now();)
+        wait_vmcnt<3>();                // block s+2 and slab s+1 have landed
+        __builtin_amdgcn_s_barrier();   // ... for every wave; and everybody is done with slab s-1 (Xt slot s-2, At[(s+1)&1], landing s+1 / s)
+        MDM_T(const unsigned long long q1 = stamp_now();)
+        // Order inside a slab: the fragment reads of the first k-step go out first; the transposing reads of the NEXT slab's operands and
+        // the DMA of the ones after are issued behind the first MFMA burst and stored behind the third -- their LDS round trip and address
+        // arithmetic sit under MFMAs instead of in front of them (every wave leaves the barrier at the same time: nothing else would run).
+        TrFrag fx, fa[2];
+        MDM_T(const unsigned long long q2 = stamp_now();)
+        const unsigned a_buf = a_frag + (unsigned)((s & 1) * (BM * TAPS_AT_PITCH));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4u_t av[MI], bc[2];
+            unsigned bm[2], bp[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) lds_read16(a_buf + (unsigned)(i * 16 * TAPS_AT_PITCH + ks * 64), av[i]);
+            const int pbase = s * 64 + ks * 32 + 8 * g4;
+            auto issue_row = [&](int dy, int b) {                 // the centre fragment of filter row dy and its two neighbour dwords
+                const int p = pbase + (dy - 1) * W;
+                lds_read16(b_row + 2u * (unsigned)(p & 255), bc[b]);
+                lds_read4(b_row + 2u * (unsigned)((p - 2) & 255), bm[b]);
+                lds_read4(b_row + 2u * (unsigned)((p + 8) & 255), bp[b]);
+            };
+            issue_row(0, 0);
+            if (ks == 1) {              // in flight: the 6 transposing reads (older), 4 + 3 fragment reads: store the transposed copies
+                wait_lgkmcnt<7>();
+                store_x(s + 2, fx);
+                store_a(s + 1, fa);
+            }
+            issue_row(1, 1);
+            // y masks of this k-step's pixel row(s)
+            const int yv = (pbase >> lw) & (H - 1);
+            const unsigned m_up = yv != 0 ? 0xFFFFFFFFu : 0u, m_dn = yv != H - 1 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int b = dy & 1;
+                // ks 0: rows 1 / 2 fly, behind them (from dy = 1 on) the 6 transposing reads.  ks 1: the 3 stores sit between row 0 and row 1.
+                if (ks == 0) { if (dy == 0) wait_lgkmcnt<3>(); else if (dy == 1) wait_lgkmcnt<9>(); else wait_lgkmcnt<6>(); }
+                else { if (dy == 0) wait_lgkmcnt<6>(); else if (dy == 1) wait_lgkmcnt<3>(); else wait_lgkmcnt<0>(); }
+                if (BIAS && do_bias && dy == 0) {
+#pragma unroll
+                    for (int i = 0; i < (BIAS ? MI : 1); ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(av[i][e] << 16) + __uint_as_float(av[i][e] & 0xFFFF0000u);
+                }
+                const unsigned my = dy == 0 ? m_up : dy == 2 ? m_dn : 0xFFFFFFFFu;
+                v4u_t c = bc[b];
+                unsigned dm = bm[b], dp = bp[b];
+                if (dy == 0) issue_row(2, 0);                     // (slot 0 is copied out: refill it behind the copy)
+                if (dy != 1) { c[0] &= my; c[1] &= my; c[2] &= my; c[3] &= my; dm &= my; dp &= my; }
+                const unsigned p1 = __builtin_amdgcn_alignbit(c[1], c[0], 16), p2 = __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                               p3 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
+                const v4u_t fl = {__builtin_amdgcn_alignbit(c[0], dm, 16) & mlo[ks], p1, p2, p3};           // pixels x-1 .. x+6
+                const v4u_t fr = {p1, p2, p3, __builtin_amdgcn_alignbit(dp, c[3], 16) & mhi[ks]};           // pixels x+1 .. x+8
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, dx == 0 ? fl : dx == 1 ? c : fr);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[dy * 3 + dx][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(bf16x8, av[i]), acc[dy * 3 + dx][i][0], 0, 0, 0);
+                }
+                if (ks == 0 && dy == 0) {
+                    transpose_x(s + 2, fx);
+                    transpose_a(s + 1, fa);
+                    issue_x(s + 4);     // into the landing stage block s+1 left (transposed during slab s-1)
+                    issue_a(s + 3);     // ... slab s left
+                }
+            }
+        }
+        MDM_T(const unsigned long long q3 = stamp_now(); tw += q1 - q0; tt += q2 - q1; tc += q3 - q2;)
+    }
+    wait_vmcnt<0>();
+    MDM_T(const unsigned long long t_loop_end = stamp_now();)
+    if (BIAS && do_bias) {              // lane (g, c) holds the sum over its k-group's pixels of channel c: add the four groups
+#pragma unroll
+        for (int i = 0; i < (BIAS ? MI : 1); ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if ((lane >> 4) == 0) atomicAdd(&d.dbias[m0 + wr * 64 + i * 16 + (lane & 15)], v);
+        }
+    }
+    // ---- nine fp32 tiles -> the gradient (uncut tile) or this item's slot, through LDS for 16-byte stores of whole rows
+    float* obase; int64_t opitch, otap;
+    if (slot) { obase = slot; opitch = BN; otap = BM * BN; }
+    else { obase = reinterpret_cast<float*>(d.D0) + (int64_t)m0 * d.N + n0; opitch = d.N; otap = d.dtap; }
+    __syncthreads();                    // every wave is done with the rings (tail DMA landed: vmcnt(0) above)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        char* buf = ring + (tp & 1) * (BM * BN * 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wr * 64 + i * 16 + (lane & 15), nl = wc * 16 + 4 * (lane >> 4);
+            *reinterpret_cast<float4*>(buf + ml * (BN * 4) + (((nl >> 2) ^ (ml & 7)) << 4)) =
+                make_float4(acc[tp][i][0][0], acc[tp][i][0][1], acc[tp][i][0][2], acc[tp][i][0][3]);
+        }
+        __syncthreads();
+        float* o = obase + tp * otap;
+#pragma unroll
+        for (int idx = t; idx < BM * (BN / 4); idx += 64 * NW) {
+            const int r = idx >> 4, q = idx & 15;
+            *reinterpret_cast<float4*>(o + r * opitch + q * 4) = *reinterpret_cast<const float4*>(buf + r * (BN * 4) + ((q ^ (r & 7)) << 4));
+        }
+    }
+#ifdef MDM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && wave == 4) {
+        const unsigned widx = 16384u + (unsigned)blockIdx.x + (unsigned)gridDim.x * (unsigned)(k0 & 31);
+        if (widx < MDM_STAMP_RECS) { unsigned long long* r = g_stamp_buf + widx * 32; r[19] = tw; r[20] = tt; r[21] = tc; }
+    }
+    if (lane == 0 && wave == 0) {
+        const unsigned widx = 16384u + (unsigned)blockIdx.x + (unsigned)gridDim.x * (unsigned)(k0 & 31);      // several items per workgroup: spread the records
+        if (widx < MDM_STAMP_RECS) {
+            unsigned long long* r = g_stamp_buf + widx * 32;
+            const unsigned long long t_end = stamp_now();
+            r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = nk; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
+            r[8] = tstart - t_entry; r[9] = t_end - t_loop_end; r[10] = t_entry;
+            r[11] = 999; r[12] = d.M; r[13] = d.N; r[14] = d.K; r[15] = stamp_hw_id(); r[16] = t_end; r[17] = 9; r[18] = slot ? 2 : 1;
+            r[0] = tw; r[1] = tt; r[2] = tc;
+        }
+    }
+#endif
+}
+
+// sums the partial slots of the tiles that mdm_wgrad_group_create cut (fixed order: slot index = position in the tile's slab range)
+struct PartTile { float* dst; long long dtap; int N, m0, n0, first_slot, parts, pad; };
+__global__ __launch_bounds__(256) void tile_parts_reduce_kernel(const PartTile* __restrict__ tab, const float* __restrict__ slots) {
+    constexpr int PER_TILE4 = TAPS_SLOT_FLOATS / 4, PIECES = PER_TILE4 / 1024;
+    const PartTile pt = tab[blockIdx.x / PIECES];
+    const int piece = blockIdx.x % PIECES;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i4 = piece * 1024 + k * 256 + threadIdx.x;
+        const float4* w = reinterpret_cast<const float4*>(slots + (int64_t)pt.first_slot * TAPS_SLOT_FLOATS) + i4;
+        float4 a = w[0];
+        for (int s2 = 1; s2 < pt.parts; ++s2) {
+            const float4 b = w[(int64_t)s2 * PER_TILE4];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const int tp = i4 / (TAPS_BM * TAPS_BN / 4), rem = i4 - tp * (TAPS_BM * TAPS_BN / 4), r = rem >> 4, q = rem & 15;
+        *reinterpret_cast<float4*>(pt.dst + tp * pt.dtap + (int64_t)(pt.m0 + r) * pt.N + pt.n0 + q * 4) = a;
+    }
 }
 
 // A GROUP of weight gradients in one launch (mdm_wgrad_group_*): the weight gradients are leaves of the backward
@@ -2044,6 +2371,27 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const mdm_gemm_desc* d
         else if (it.w == 1) wgrad_lin_body<128, 128, 3, 8>(d, it.y, it.z);
         else wgrad_lin_body<64, 64, 4, 8>(d, it.y, it.z);
         __syncthreads();            // the next item refills the LDS ring
+    }
+}
+// The nine-tap layers of a group: grid = CUs, workgroup q walks column q of table[round][queue] (one share per CU, equal by
+// construction: mdm_wgrad_group_create).  item = {descriptor, tile | (slot + 1) << 12, k0 | k1 << 16, 3}.
+__global__ __launch_bounds__(512) void wgrad_taps_group_kernel(const mdm_gemm_desc* descs, const int4* items, int n_items, float* slots) {
+    for (int i = blockIdx.x; i < n_items; i += gridDim.x) {
+        int4 it = items[i];
+        it.x = __builtin_amdgcn_readfirstlane(it.x); it.y = __builtin_amdgcn_readfirstlane(it.y); it.z = __builtin_amdgcn_readfirstlane(it.z);
+        it.w = __builtin_amdgcn_readfirstlane(it.w);
+        if (it.x < 0) continue;
+        const mdm_gemm_desc& d = descs[it.x];       // (fields are read where they are used: a copy would sit in registers next to 144 accumulators)
+        float* slot = (it.y >> 12) ? slots + (int64_t)((it.y >> 12) - 1) * TAPS_SLOT_FLOATS : nullptr;
+        const int tile = it.y & 4095, k0 = it.z & 0xFFFF, k1 = (int)((unsigned)it.z >> 16);
+        if (it.w != 3) {                    // a per-tap item that rides in this CU's queue (1x1 projections, 8-channel / stride-2 / 4x4 layers)
+            const mdm_gemm_desc dc = d;
+            if (it.w == 2) wgrad_lin_body<256, 128, 3, 8>(dc, it.y, it.z);
+            else if (it.w == 1) wgrad_lin_body<128, 128, 3, 8>(dc, it.y, it.z);
+            else wgrad_lin_body<64, 64, 4, 8>(dc, it.y, it.z);
+        } else if (d.dbias != nullptr && tile % (d.N / TAPS_BN) == 0) wgrad_taps_body<true>(d, tile, k0, k1, slot);
+        else wgrad_taps_body<false>(d, tile, k0, k1, slot);
+        __syncthreads();
     }
 }
 
@@ -2469,6 +2817,17 @@ static bool wgrad_lin_eligible(const mdm_gemm_desc& d) {
     return d.stride == 1 && d.ups == 1 && ((64 / d.OW) & 1) == 0;                   // folded nearest x2 upsample
 }
 
+// all nine taps in one pass (wgrad_taps_body); MDM_WGRAD_TAPS=0 keeps every layer on the per-tap kernel (A/B runs)
+static bool wgrad_taps_eligible(const mdm_gemm_desc& d) {
+    static const bool off = [] { const char* e = getenv("MDM_WGRAD_TAPS"); return e && atoi(e) == 0; }();
+    if (off) return false;
+    return d.dtype == MDM_BF16 && d.layout == 2 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 &&
+           (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.OH >= 2 && (d.OH & (d.OH - 1)) == 0 && d.OH * d.OW >= 64 && d.IH == d.OH && d.IW == d.OW &&
+           (d.ups == 0 || d.ups == 1) && d.M % TAPS_BM == 0 && d.N % TAPS_BN == 0 && d.N / TAPS_BN * (d.M / TAPS_BM) <= 4095 && d.K % 64 == 0 &&
+           d.K / 64 < 65535 && d.C0 % 8 == 0 && d.C1 % 8 == 0 && d.N == d.C0 + d.C1 && d.out_f32 && !d.acc0 && d.ldd0 == d.N && d.N0 == d.N &&
+           d.alpha == 1.0f && d.dtap == (int64_t)d.M * d.N;
+}
+
 static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of one halo buffer
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
@@ -2802,8 +3161,14 @@ struct WgradGroup {
     int n_items = 0, max_blocks = 0;
     std::vector<ReduceTable> reduces;       // the split-K sums of the group's split layers: passed by value at launch
     std::vector<int> reduce_blocks;
+    const int4* taps_items_dev = nullptr;   // the nine-tap layers: table[round][CU] of the persistent launch
+    int n_taps_items = 0, taps_blocks = 0;
+    float* slots_dev = nullptr;             // nine-tap tiles that were cut: partial sums [slot][9][128][64]
+    const PartTile* parts_dev = nullptr;
+    int n_part_tiles = 0;
 };
 struct GroupItem { int desc, item, tiles_x, big, cost; };
+struct TapsTile { int desc, tile, slabs; };
 
 }  // namespace mdm
 using namespace mdm;
@@ -2896,12 +3261,105 @@ extern "C" int mdm_wgrad_group_accepts(const mdm_gemm_desc* desc_host) {
     if (d.N0 == 0) d.N0 = d.N;
     return wgrad_lin_eligible(d) && d.out_f32 && d.N0 == d.N && d.ldd0 == d.N && d.dtap == (int64_t)d.M * d.N ? 1 : 0;
 }
+// Schedule of a group's nine-tap layers: ONE queue per CU, walked by one persistent workgroup (grid = CUs, table[round][queue]).
+// The (tile, slab) space is poured over the queues in order, every queue up to the common level -- a tile is cut where a queue
+// is full, so the shares are equal by construction and a tile has only as many partial slots as CUs that worked on it.
+// Costs in shader cycles per slab / per item, from in-kernel stamps (scripts/stamp_group.py).
+static void build_taps_schedule(const std::vector<mdm_gemm_desc>& ds, const std::vector<TapsTile>& tt, const std::vector<GroupItem>& legacy, int NQ,
+                                std::vector<int4>& table, std::vector<PartTile>& parts, int& nslots) {
+    static const double CF = [] { const char* e = getenv("MDM_TAPS_SLAB_COST"); return e ? atof(e) : 4350.0; }();
+    static const double FF = [] { const char* e = getenv("MDM_TAPS_ITEM_COST"); return e ? atof(e) : 25000.0; }();
+    const int MINPART = 8;
+    std::vector<std::vector<int4>> fq((size_t)NQ), lq((size_t)NQ);
+    std::vector<double> load((size_t)NQ, 0.0);
+    double total = 0.0;
+    {   // the per-tap items of the group (1x1 projections, 8-channel / stride-2 / 4x4 layers) ride in the same queues: longest first
+        // onto the least loaded one; the nine-tap shares then fill every queue up to the common level
+        auto cost = [&](const GroupItem& gi) -> double {
+            const mdm_gemm_desc& d = ds[(size_t)gi.desc];
+            const int sk = d.splitk < 1 ? 1 : d.splitk;
+            const int chunk = ((d.K + sk - 1) / sk + 63) / 64 * 64;
+            const int ks = gi.item / (gi.tiles_x * d.KH * d.KW);
+            int len = d.K - ks * chunk; if (len > chunk) len = chunk;
+            const double slabs = len / 64.0;
+            return gi.big == 2 ? slabs * 2500 + 11000 : gi.big == 1 ? slabs * 1510 + 5700 : slabs * 1050 + 3000;
+        };
+        std::vector<std::pair<double, int>> order;
+        for (size_t a = 0; a < legacy.size(); ++a) order.push_back({cost(legacy[a]), (int)a});
+        std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+        for (const auto& o : order) {
+            int qq = 0;
+            for (int x = 1; x < NQ; ++x) if (load[(size_t)x] < load[(size_t)qq]) qq = x;
+            const GroupItem& gi = legacy[(size_t)o.second];
+            lq[(size_t)qq].push_back(make_int4(gi.desc, gi.item, gi.tiles_x, gi.big));
+            load[(size_t)qq] += o.first; total += o.first;
+        }
+    }
+    double slabs_total = 0.0;
+    for (const auto& t : tt) slabs_total += t.slabs;
+    double level = (total + slabs_total * CF + ((double)tt.size() + NQ) * FF) / NQ;
+    const std::vector<double> base_load = load;
+    // pour the nine-tap tiles; a part is never shorter than MINPART slabs.  What does not fit (every queue keeps up to MINPART slabs
+    // of room) would all land in the last queue: raise the level until the last queue is no higher than the others.
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        load = base_load; parts.clear(); nslots = 0;
+        for (auto& v : fq) v.clear();
+        int q = 0;
+        for (const auto& t : tt) {
+            const mdm_gemm_desc& d = ds[(size_t)t.desc];
+            struct Part { int q, k0, k1; };
+            std::vector<Part> ps;
+            int k = 0;
+            while (k < t.slabs) {
+                const int rem = t.slabs - k;
+                int room = (int)((level - load[(size_t)q] - FF) / CF);
+                if (q == NQ - 1) room = rem;
+                if (room < MINPART && q < NQ - 1) { ++q; continue; }
+                int take = room < rem ? room : rem;
+                if (rem - take > 0 && rem - take < MINPART) take = rem;
+                ps.push_back(Part{q, k, k + take});
+                load[(size_t)q] += take * CF + FF;
+                k += take;
+            }
+            const int tiles_n = d.N / TAPS_BN, tm = t.tile / tiles_n, tn = t.tile - tm * tiles_n;
+            if (ps.size() > 1) {
+                PartTile pt;
+                pt.dst = reinterpret_cast<float*>(d.D0); pt.dtap = d.dtap; pt.N = d.N; pt.m0 = tm * TAPS_BM; pt.n0 = tn * TAPS_BN;
+                pt.first_slot = nslots; pt.parts = (int)ps.size(); pt.pad = 0;
+                parts.push_back(pt);
+            }
+            for (size_t a2 = 0; a2 < ps.size(); ++a2) {
+                const int slot1 = ps.size() > 1 ? nslots + (int)a2 + 1 : 0;
+                fq[(size_t)ps[a2].q].push_back(make_int4(t.desc, t.tile | (slot1 << 12), ps[a2].k0 | (ps[a2].k1 << 16), 3));
+            }
+            if (ps.size() > 1) nslots += (int)ps.size();
+        }
+        if (load[(size_t)NQ - 1] <= level * 1.01) break;
+        level *= 1.015;
+    }
+    size_t rounds = 0;
+    for (int x = 0; x < NQ; ++x) {
+        fq[(size_t)x].insert(fq[(size_t)x].end(), lq[(size_t)x].begin(), lq[(size_t)x].end());
+        rounds = fq[(size_t)x].size() > rounds ? fq[(size_t)x].size() : rounds;
+    }
+    table.assign(rounds * (size_t)NQ, make_int4(-1, 0, 0, 0));
+    for (int x = 0; x < NQ; ++x)
+        for (size_t w = 0; w < fq[(size_t)x].size(); ++w) table[w * (size_t)NQ + (size_t)x] = fq[(size_t)x][w];
+    if (getenv("MDM_TAPS_DEBUG")) {
+        double lo = 1e30, hi = 0;
+        for (int x = 0; x < NQ; ++x) { lo = load[(size_t)x] < lo ? load[(size_t)x] : lo; hi = load[(size_t)x] > hi ? load[(size_t)x] : hi; }
+        fprintf(stderr, "[mdm] wgrad group: %zu nine-tap tiles (%.0f slabs) + %zu per-tap items, %d queues x %zu rounds, level %.0f, load %.0f..%.0f, %zu cut tiles, %d slots\n",
+                tt.size(), slabs_total, legacy.size(), NQ, rounds, level, lo, hi, parts.size(), nslots);
+    }
+}
+
 extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, void* dev_buf, int64_t dev_bytes,
                                       int64_t* need_bytes_out, void** handle_out) {
     MDM_REQUIRE(descs_host && n > 0 && need_bytes_out && handle_out, "wgrad_group_create: bad arguments");
     *handle_out = nullptr;
     std::vector<mdm_gemm_desc> ds((size_t)n);
     std::vector<GroupItem> items;
+    std::vector<TapsTile> taps_tiles;
     WgradGroup* g = new WgradGroup();
     ReduceTable tab;
     tab.n = 0;
@@ -2915,6 +3373,13 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         if (int rc = resolve(descs_host + i, false, r)) { delete g; return rc; }
         if (!mdm_wgrad_group_accepts(&r.d)) { delete g; set_error("wgrad_group_create: descriptor %d is not a groupable weight gradient", i); return -1; }
         if (r.d.splitk > 1 && !r.d.ws) { delete g; set_error("wgrad_group_create: descriptor %d is split %d ways but has no workspace of its own", i, r.d.splitk); return -1; }
+        if (wgrad_taps_eligible(r.d)) {             // all nine taps per work item: cut into per-CU shares below, no split-K slabs
+            r.d.splitk = 1;
+            ds[(size_t)i] = r.d;
+            const int tiles = (r.d.M / TAPS_BM) * (r.d.N / TAPS_BN);
+            for (int tl = 0; tl < tiles; ++tl) taps_tiles.push_back(TapsTile{i, tl, r.d.K / 64});
+            continue;
+        }
         ds[(size_t)i] = r.d;
         const mdm_gemm_desc& d = r.d;
         const int BK = 64, sk = d.splitk < 1 ? 1 : d.splitk;
@@ -2964,23 +3429,47 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
     }
     size_t maxlen = 0;
     for (const auto& qv : queue) maxlen = qv.size() > maxlen ? qv.size() : maxlen;
-    const size_t n_slots = 8 * maxlen;
-    const int64_t desc_bytes = ((int64_t)n * (int64_t)sizeof(mdm_gemm_desc) + 255) / 256 * 256;
-    const int64_t need = desc_bytes + (int64_t)n_slots * 16;
+    const size_t n_slots_lin = 8 * maxlen;
+    // the nine-tap layers: their own table, launch and partial slots
+    static const int n_cu = [] {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
+        return pr.multiProcessorCount;
+    }();
+    std::vector<int4> taps_table;
+    std::vector<PartTile> parts;
+    int nslots = 0;
+    const bool merged = !taps_tiles.empty();        // a group with nine-tap layers runs as ONE persistent launch, its per-tap items in the same queues
+    if (merged) build_taps_schedule(ds, taps_tiles, items, n_cu, taps_table, parts, nslots);
+    const size_t n_slots = merged ? 0 : n_slots_lin;
+    auto pad256 = [](int64_t v) { return (v + 255) / 256 * 256; };
+    const int64_t desc_bytes = pad256((int64_t)n * (int64_t)sizeof(mdm_gemm_desc));
+    const int64_t item_bytes = pad256((int64_t)n_slots * 16), titem_bytes = pad256((int64_t)taps_table.size() * 16);
+    const int64_t part_bytes = pad256((int64_t)parts.size() * (int64_t)sizeof(PartTile));
+    const int64_t need = desc_bytes + item_bytes + titem_bytes + part_bytes + (int64_t)nslots * TAPS_SLOT_FLOATS * 4;
     *need_bytes_out = need;
     if (!dev_buf || dev_bytes < need) { delete g; return 0; }      // size query
     std::vector<int4> it4(n_slots, make_int4(-1, 0, 0, 0));
-    for (int x = 0; x < 8; ++x)
+    for (int x = 0; x < 8 && !merged; ++x)
         for (size_t w = 0; w < queue[(size_t)x].size(); ++w) {
             const GroupItem& gi = items[(size_t)queue[(size_t)x][w]];
             it4[w * 8 + (size_t)x] = make_int4(gi.desc, gi.item, gi.tiles_x, gi.big);      // slot of workgroup b = w * 8 + x
         }
-    hipError_t e = hipMemcpy(dev_buf, ds.data(), (size_t)n * sizeof(mdm_gemm_desc), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(dev_buf) + desc_bytes, it4.data(), it4.size() * 16, hipMemcpyHostToDevice);
+    char* base = reinterpret_cast<char*>(dev_buf);
+    hipError_t e = hipMemcpy(base, ds.data(), (size_t)n * sizeof(mdm_gemm_desc), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !it4.empty()) e = hipMemcpy(base + desc_bytes, it4.data(), it4.size() * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !taps_table.empty()) e = hipMemcpy(base + desc_bytes + item_bytes, taps_table.data(), taps_table.size() * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !parts.empty()) e = hipMemcpy(base + desc_bytes + item_bytes + titem_bytes, parts.data(), parts.size() * sizeof(PartTile), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete g; return hip_fail(e, "wgrad_group_create: hipMemcpy"); }
-    g->descs_dev = reinterpret_cast<const mdm_gemm_desc*>(dev_buf);
-    g->items_dev = reinterpret_cast<const int4*>(reinterpret_cast<char*>(dev_buf) + desc_bytes);
+    g->descs_dev = reinterpret_cast<const mdm_gemm_desc*>(base);
+    g->items_dev = reinterpret_cast<const int4*>(base + desc_bytes);
     g->n_items = (int)n_slots;
+    g->taps_items_dev = reinterpret_cast<const int4*>(base + desc_bytes + item_bytes);
+    g->n_taps_items = (int)taps_table.size();
+    g->taps_blocks = n_cu;
+    g->parts_dev = reinterpret_cast<const PartTile*>(base + desc_bytes + item_bytes + titem_bytes);
+    g->slots_dev = reinterpret_cast<float*>(base + desc_bytes + item_bytes + titem_bytes + part_bytes);
+    g->n_part_tiles = (int)parts.size();
     *handle_out = g;
     return 0;
 }
@@ -2992,12 +3481,21 @@ extern "C" int mdm_wgrad_group_launch(void* handle, void* stream) {
     static bool configured = false;
     if (!configured) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        configured = true;
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
-    const int nb = (g->max_blocks > 0 && g->max_blocks < g->n_items) ? g->max_blocks : g->n_items;
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)nb), dim3(512), bytes, s, g->descs_dev, g->items_dev, g->n_items);
+    configured = true;
+    if (g->n_taps_items > 0) {
+        const int tb = g->taps_blocks < g->n_taps_items ? g->taps_blocks : g->n_taps_items;
+        hipLaunchKernelGGL(wgrad_taps_group_kernel, dim3((unsigned)tb), dim3(512), bytes, s, g->descs_dev, g->taps_items_dev, g->n_taps_items, g->slots_dev);
+    }
+    if (g->n_items > 0) {
+        const int nb = (g->max_blocks > 0 && g->max_blocks < g->n_items) ? g->max_blocks : g->n_items;
+        hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)nb), dim3(512), bytes, s, g->descs_dev, g->items_dev, g->n_items);
+    }
     for (size_t i = 0; i < g->reduces.size(); ++i)
         hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)g->reduce_blocks[i]), dim3(256), 0, s, g->reduces[i]);
+    if (g->n_part_tiles > 0)
+        hipLaunchKernelGGL(tile_parts_reduce_kernel, dim3((unsigned)(g->n_part_tiles * (TAPS_SLOT_FLOATS / 4 / 1024))), dim3(256), 0, s, g->parts_dev, g->slots_dev);
     return launch_status("wgrad group");
 }
 extern "C" int mdm_wgrad_group_destroy(void* handle) {
@@ -3006,12 +3504,14 @@ extern "C" int mdm_wgrad_group_destroy(void* handle) {
 }
 
 #ifdef MDM_STAMP
-extern "C" int mdm_debug_stamps(unsigned long long* out, int reset) {      // out: 4096 * 32 entries
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdm::g_stamp_buf), 4096 * 32 * 8) != hipSuccess) return -1;
+extern "C" int mdm_debug_stamps_n(unsigned long long* out, int n_records, int reset) {      // out: n_records * 32 entries
+    if (n_records < 1 || n_records > MDM_STAMP_RECS) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdm::g_stamp_buf), (size_t)n_records * 32 * 8) != hipSuccess) return -1;
     if (reset) {
         void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mdm::g_stamp_buf)) != hipSuccess || hipMemset(p, 0, 4096 * 32 * 8) != hipSuccess) return -1;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mdm::g_stamp_buf)) != hipSuccess || hipMemset(p, 0, (size_t)n_records * 32 * 8) != hipSuccess) return -1;
     }
     return 0;
 }
+extern "C" int mdm_debug_stamps(unsigned long long* out, int reset) { return mdm_debug_stamps_n(out, 4096, reset); }
 #endif

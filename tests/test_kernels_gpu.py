@@ -506,9 +506,13 @@ def test_grouped_weight_gradients_match_self_contained_ones():
     dt = "bf16"
     g = torch.Generator().manual_seed(77)
     shapes = [(8, 8, 64, 0, 64, 1, 0), (8, 8, 64, 0, 128, 1, 0), (4, 16, 64, 64, 64, 1, 0), (4, 32, 128, 0, 128, 1, 0),
-              (8, 16, 64, 0, 64, 2, 0), (4, 8, 64, 0, 64, 1, 1), (16, 4, 256, 0, 256, 1, 0)]      # N, H, C0, C1, Cout, stride, ups
+              (8, 16, 64, 0, 64, 2, 0), (4, 8, 64, 0, 64, 1, 1), (16, 4, 256, 0, 256, 1, 0),      # N, H, C0, C1, Cout, stride, ups
+              # all nine taps in one pass (wgrad_taps_body: 128 | Cout, 64 | Cin, maps 8 / 16 / 32 wide): concat, folded upsample,
+              # two output-channel tiles, tiles cut over several CUs (partial slots + tile_parts_reduce_kernel)
+              (4, 8, 64, 64, 128, 1, 0), (4, 16, 64, 64, 128, 1, 0), (2, 16, 128, 0, 128, 1, 1), (4, 4, 64, 0, 128, 1, 1),
+              (2, 32, 64, 0, 256, 1, 0)]
     jobs = []
-    for rep in range(231):
+    for rep in range(240):
         N, H, C0, C1, Cout, stride, ups = shapes[rep % len(shapes)]
         pads = (1, 1, 1, 1) if stride == 1 else (0, 0, 1, 1)
         geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, stride=stride, pad_t=pads[0], pad_l=pads[1], pad_b=pads[2],
@@ -516,7 +520,7 @@ def test_grouped_weight_gradients_match_self_contained_ones():
         x0 = _up(_nhwc(_q(torch.randn(N, C0, H, H, generator=g), dt)), dt)
         x1 = _up(_nhwc(_q(torch.randn(N, C1, H, H, generator=g), dt)), dt) if C1 else None
         gy = _up(_nhwc(_q(torch.randn(N, Cout, geom.OH, geom.OW, generator=g), dt)), dt)
-        jobs.append((geom, x0, x1, gy, rep % 3 == 0))
+        jobs.append((geom, x0, x1, gy, rep % 5 == 0))
     want = []
     for geom, x0, x1, gy, acc in jobs:
         nb = ops.conv_wgrad_ws_bytes(1, geom)
