@@ -3368,12 +3368,29 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         if (tab.n > 0) { tab.first_block[tab.n] = blocks; g->reduces.push_back(tab); g->reduce_blocks.push_back(blocks); }
         tab.n = 0; blocks = 0;
     };
+    static const int n_cu = [] {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
+        return pr.multiProcessorCount;
+    }();
+    // The nine-tap kernel pays ~30 000 cycles per work item around its loop (two DMA round trips + transposes in front, nine fp32 tiles
+    // behind) and a launch that sums the cut tiles' slots; its loop is ~1.3x faster per flop than the per-tap tiles'.  Per group
+    // (profiles/r03_wgrad_taps_stamps.txt): the decoder's 32x32 / 16x16 layers (94 slabs per CU) 392 -> 330 us, the encoder's (34 slabs per
+    // CU) and the 8x8 maps' (10 per CU) came out 10-40 % slower.  So: only where a CU's share is long.
+    const char* ms_env = getenv("MDM_TAPS_MIN_SHARE");          // (read per group: the kernel test forces the path on a small group)
+    const int min_share = ms_env ? atoi(ms_env) : 48;
+    long long taps_slabs = 0;
+    for (int i = 0; i < n; ++i) {
+        Resolved r;
+        if (resolve(descs_host + i, false, r) == 0 && wgrad_taps_eligible(r.d)) taps_slabs += (long long)(r.d.M / TAPS_BM) * (r.d.N / TAPS_BN) * (r.d.K / 64);
+    }
+    const bool use_taps = taps_slabs >= (long long)min_share * n_cu;
     for (int i = 0; i < n; ++i) {
         Resolved r;
         if (int rc = resolve(descs_host + i, false, r)) { delete g; return rc; }
         if (!mdm_wgrad_group_accepts(&r.d)) { delete g; set_error("wgrad_group_create: descriptor %d is not a groupable weight gradient", i); return -1; }
         if (r.d.splitk > 1 && !r.d.ws) { delete g; set_error("wgrad_group_create: descriptor %d is split %d ways but has no workspace of its own", i, r.d.splitk); return -1; }
-        if (wgrad_taps_eligible(r.d)) {             // all nine taps per work item: cut into per-CU shares below, no split-K slabs
+        if (use_taps && wgrad_taps_eligible(r.d)) {             // all nine taps per work item: cut into per-CU shares below, no split-K slabs
             r.d.splitk = 1;
             ds[(size_t)i] = r.d;
             const int tiles = (r.d.M / TAPS_BM) * (r.d.N / TAPS_BN);
@@ -3431,11 +3448,6 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
     for (const auto& qv : queue) maxlen = qv.size() > maxlen ? qv.size() : maxlen;
     const size_t n_slots_lin = 8 * maxlen;
     // the nine-tap layers: their own table, launch and partial slots
-    static const int n_cu = [] {
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
-        return pr.multiProcessorCount;
-    }();
     std::vector<int4> taps_table;
     std::vector<PartTile> parts;
     int nslots = 0;

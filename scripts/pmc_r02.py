@@ -12,7 +12,7 @@ def rows(kind):
 
 
 def family(k):
-    if any(x in k for x in ("conv_halo", "conv_lin2", "conv_pair", "wgrad_group", "wgrad_lin", "gemm_ring", "gemm_bf16", "splitk_")):
+    if any(x in k for x in ("conv_halo", "conv_lin2", "conv_pair", "wgrad_group", "wgrad_taps", "tile_parts_reduce", "wgrad_lin", "gemm_ring", "gemm_bf16", "splitk_")):
         return "contraction"
     if "attn_" in k: return "attention"
     if "gn_" in k: return "groupnorm"

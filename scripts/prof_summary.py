@@ -9,7 +9,7 @@ def cat(n):
     if "gemm_ring_kernel" in n: return "wgrad ring<.,.,2" if ", 2, " in n.split("(")[0] else "gemm_ring other"
     if "conv_pair" in n: return "conv_pair"
     if "conv_lin" in n: return "conv_lin"
-    if "wgrad_lin" in n or "wgrad_group" in n: return "wgrad_lin"
+    if "wgrad_lin" in n or "wgrad_group" in n or "wgrad_taps" in n or "tile_parts_reduce" in n: return "wgrad_lin"
     if "conv_halo" in n: return "conv_halo"
     for k in ("gemm_bf16", "gemm_f32", "splitk_reduce", "splitk_epilogue", "gn_bwd", "gn_fwd", "softmax"):
         if k in n: return k

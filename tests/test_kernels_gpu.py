@@ -4,6 +4,8 @@ order).  bf16 path: inputs are pre-rounded to bf16 so only accumulation order an
 final bf16 store differ."""
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -545,7 +547,15 @@ def test_grouped_weight_gradients_match_self_contained_ones():
             keep.append(ws)
         fields.append(wf); got.append((gw, gb, acc))
     assert n_split > 96
-    grp = _lib.WgradGroup(fields, _dev())
+    old = os.environ.get("MDM_TAPS_MIN_SHARE")
+    os.environ["MDM_TAPS_MIN_SHARE"] = "0"            # the nine-tap path is taken only where a CU's share is long: force it for this small group
+    try:
+        grp = _lib.WgradGroup(fields, _dev())
+    finally:
+        if old is None:
+            del os.environ["MDM_TAPS_MIN_SHARE"]
+        else:
+            os.environ["MDM_TAPS_MIN_SHARE"] = old
     grp.launch()
     torch.cuda.synchronize()
     for (a, ab, acc), (b, bb) in zip(got, want):
