@@ -253,13 +253,16 @@ def bench_cut_graph(mdm, TrainStep, model, sched, args, optim, ema, used, opt_, 
     firing with world = 1 -- next to the one-graph form, same model, same box, back to back."""
     a2 = argparse.Namespace(**vars(args))
     a2.cut_step_graph = True
+    # a rank of a data-parallel job groups its weight gradients in ~32 MB buckets (UNet's default once torch.distributed is up):
+    # the same weights and optimizer, a second launch plan
+    model = mdm.UNet(model.cfg, N=model.N, H=model.H, W=model.W, dtype=model.dt, store=model.store, wgrad_group_bytes=32 << 20)
     cut = TrainStep(model, sched, a2, optim, ema, mean_shift=True, comm=None)
     cut.x0.copy_(torch.rand(model.N, 3, model.H, model.W) * 2 - 1)
     ms = time_steps(cut, used, opt_.warmup, opt_.steps)
     pieces = len(cut._graphs[2]) + (1 if cut._graphs[3] is not None else 0)
     log(f"cut-graph form: {ms:.4f} ms/step in {pieces} backward pieces (+ front + tail) vs {whole_ms:.4f} whole")
     return {"ms_per_step": round(ms, 4), "whole_graph_ms_per_step": round(whole_ms, 4), "ratio": round(ms / whole_ms, 4),
-            "graphs_per_step": pieces + 2, "note": "front / bucket pieces / tail hipGraphs, bucket hooks with world = 1 (no exchange)"}
+            "graphs_per_step": pieces + 2, "note": "front / bucket pieces / tail hipGraphs over 32 MB weight-gradient groups, bucket hooks with world = 1 (no exchange); the one-graph form runs one group"}
 
 
 def bench_config(mdm, _lib, TrainStep, name, dev, opt_):
