@@ -2053,7 +2053,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_lin_kernel(mdm_gemm_desc d, int
 // Work item = (tile, range of slabs [k0, k1)): the host cuts the (tile, slab) space of a whole group into one contiguous
 // share per CU (mdm_wgrad_group_create), so a tile that is cut writes its partial sums to a `slot` ([9][128][64] fp32) and
 // tile_parts_reduce_kernel adds the slots; an uncut tile goes straight to the gradient.
-// Requires: 3x3, stride 1, pad 1, OW in {8, 16, 32}, OH a power of two, OH OW >= 64, M % 128 == 0, N % 64 == 0, bf16.
+// Requires: 3x3, stride 1, pad 1, OW in {8, 16, 32}, OH a power of two, OH OW >= 64, bf16; M a multiple of 128 or one partly filled
+// tile (M < 128, 8 | M), N a multiple of 64 or one partly filled tile: the two 8-channel ends of the U-Net ride along on zero operands.
 // ----------------------------------------------------------------------------
 constexpr int TAPS_BM = 128, TAPS_BN = 64, TAPS_SLOT_FLOATS = 9 * TAPS_BM * TAPS_BN;
 constexpr int TAPS_XL = 0, TAPS_XT = 3 * 8192, TAPS_XT_PITCH = 528, TAPS_AL = TAPS_XT + 64 * TAPS_XT_PITCH, TAPS_AT = TAPS_AL + 3 * 16384,
@@ -2084,11 +2085,12 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tiles_n = d.N / BN;
+    const int tiles_n = (d.N + BN - 1) / BN;
     const int tile_m = udiv_small(tile_i, tiles_n);
     const int m0 = tile_m * BM, n0 = (tile_i - tile_m * tiles_n) * BN;
     const int W = d.OW, H = d.OH, lw = __builtin_ctz(d.OW), lh = __builtin_ctz(d.OH);
     const int nk = k1 - k0, total_slabs = d.K >> 6;
+    const int rows = min(BM, d.M - m0), cols = min(BN, d.N - n0);        // an 8-channel end of the net is ONE partly filled tile (zero operands)
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)ring;
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -2100,7 +2102,7 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
     for (int j = 0; j < 2; ++j) {
         const int kl = (wave * 2 + j) * 4 + (lane >> 4);
         const int gm = m0 + 8 * ((lane & 15) ^ swz_cols<16>(kl));
-        pa[j] = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.A) + ((int64_t)k0 * 64 + kl) * d.lda + gm);
+        pa[j] = gm < d.M ? reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.A) + ((int64_t)k0 * 64 + kl) * d.lda + gm) : nullptr;
     }
     // input pixels: [64 pixels][64 channels] per block, one piece (8 pixel rows) per wave
     const int xrow = 8 * wave + (lane >> 3);
@@ -2110,7 +2112,7 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
     const bf16_t* const xS = reinterpret_cast<const bf16_t*>(xs1 ? d.src1 : d.src0) + (xs1 ? xgn - d.C0 : xgn);
     const int ups = d.ups;
     auto x_src = [&](int blk) -> const char* {                    // where block `blk` (pixels 64 blk ..) comes from
-        if (blk < 0 || blk >= total_slabs || blk > k1) return zlane;
+        if (blk < 0 || blk >= total_slabs || blk > k1 || xgn >= d.N) return zlane;
         const int p = blk * 64 + xrow;
         int phys = p;
         if (ups) {
@@ -2125,8 +2127,8 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
         char* dst = ring + TAPS_AL + stage3(slab) * 16384;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            lds_dma16(live ? pa[j] : zlane, dst + (wave * 2 + j) * 1024);
-            pa[j] += a_step;
+            lds_dma16(live && pa[j] ? pa[j] : zlane, dst + (wave * 2 + j) * 1024);
+            if (pa[j]) pa[j] += a_step;
         }
     };
     auto issue_x = [&](int blk) { lds_dma16(x_src(blk), ring + TAPS_XL + stage3(blk) * 8192 + wave * 1024); };
@@ -2286,7 +2288,7 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
             float v = bsum[i];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if ((lane >> 4) == 0) atomicAdd(&d.dbias[m0 + wr * 64 + i * 16 + (lane & 15)], v);
+            if ((lane >> 4) == 0 && wr * 64 + i * 16 + (lane & 15) < rows) atomicAdd(&d.dbias[m0 + wr * 64 + i * 16 + (lane & 15)], v);
         }
     }
     // ---- nine fp32 tiles -> the gradient (uncut tile) or this item's slot, through LDS for 16-byte stores of whole rows
@@ -2308,7 +2310,8 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
 #pragma unroll
         for (int idx = t; idx < BM * (BN / 4); idx += 64 * NW) {
             const int r = idx >> 4, q = idx & 15;
-            *reinterpret_cast<float4*>(o + r * opitch + q * 4) = *reinterpret_cast<const float4*>(buf + r * (BN * 4) + ((q ^ (r & 7)) << 4));
+            if (slot || (r < rows && q * 4 < cols))
+                *reinterpret_cast<float4*>(o + r * opitch + q * 4) = *reinterpret_cast<const float4*>(buf + r * (BN * 4) + ((q ^ (r & 7)) << 4));
         }
     }
 #ifdef MDM_STAMP
@@ -2332,7 +2335,7 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
 }
 
 // sums the partial slots of the tiles that mdm_wgrad_group_create cut (fixed order: slot index = position in the tile's slab range)
-struct PartTile { float* dst; long long dtap; int N, m0, n0, first_slot, parts, pad; };
+struct PartTile { float* dst; long long dtap; int N, m0, n0, first_slot, parts, rows, cols, pad; };
 __global__ __launch_bounds__(256) void tile_parts_reduce_kernel(const PartTile* __restrict__ tab, const float* __restrict__ slots) {
     constexpr int PER_TILE4 = TAPS_SLOT_FLOATS / 4, PIECES = PER_TILE4 / 1024;
     const PartTile pt = tab[blockIdx.x / PIECES];
@@ -2347,7 +2350,7 @@ __global__ __launch_bounds__(256) void tile_parts_reduce_kernel(const PartTile* 
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         const int tp = i4 / (TAPS_BM * TAPS_BN / 4), rem = i4 - tp * (TAPS_BM * TAPS_BN / 4), r = rem >> 4, q = rem & 15;
-        *reinterpret_cast<float4*>(pt.dst + tp * pt.dtap + (int64_t)(pt.m0 + r) * pt.N + pt.n0 + q * 4) = a;
+        if (r < pt.rows && q * 4 < pt.cols) *reinterpret_cast<float4*>(pt.dst + tp * pt.dtap + (int64_t)(pt.m0 + r) * pt.N + pt.n0 + q * 4) = a;
     }
 }
 
@@ -2389,7 +2392,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_group_kernel(const mdm_gemm_de
             if (it.w == 2) wgrad_lin_body<256, 128, 3, 8>(dc, it.y, it.z);
             else if (it.w == 1) wgrad_lin_body<128, 128, 3, 8>(dc, it.y, it.z);
             else wgrad_lin_body<64, 64, 4, 8>(dc, it.y, it.z);
-        } else if (d.dbias != nullptr && tile % (d.N / TAPS_BN) == 0) wgrad_taps_body<true>(d, tile, k0, k1, slot);
+        } else if (d.dbias != nullptr && tile % ((d.N + TAPS_BN - 1) / TAPS_BN) == 0) wgrad_taps_body<true>(d, tile, k0, k1, slot);
         else wgrad_taps_body<false>(d, tile, k0, k1, slot);
         __syncthreads();
     }
@@ -2823,7 +2826,8 @@ static bool wgrad_taps_eligible(const mdm_gemm_desc& d) {
     if (off) return false;
     return d.dtype == MDM_BF16 && d.layout == 2 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 &&
            (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.OH >= 2 && (d.OH & (d.OH - 1)) == 0 && d.OH * d.OW >= 64 && d.IH == d.OH && d.IW == d.OW &&
-           (d.ups == 0 || d.ups == 1) && d.M % TAPS_BM == 0 && d.N % TAPS_BN == 0 && d.N / TAPS_BN * (d.M / TAPS_BM) <= 4095 && d.K % 64 == 0 &&
+           (d.ups == 0 || d.ups == 1) && (d.M % TAPS_BM == 0 || (d.M < TAPS_BM && d.M % 8 == 0)) && (d.N % TAPS_BN == 0 || (d.N < TAPS_BN && d.N % 8 == 0)) &&
+           cdiv(d.N, TAPS_BN) * cdiv(d.M, TAPS_BM) <= 4095 && d.K % 64 == 0 &&
            d.K / 64 < 65535 && d.C0 % 8 == 0 && d.C1 % 8 == 0 && d.N == d.C0 + d.C1 && d.out_f32 && !d.acc0 && d.ldd0 == d.N && d.N0 == d.N &&
            d.alpha == 1.0f && d.dtap == (int64_t)d.M * d.N;
 }
@@ -3321,11 +3325,12 @@ static void build_taps_schedule(const std::vector<mdm_gemm_desc>& ds, const std:
                 load[(size_t)q] += take * CF + FF;
                 k += take;
             }
-            const int tiles_n = d.N / TAPS_BN, tm = t.tile / tiles_n, tn = t.tile - tm * tiles_n;
+            const int tiles_n = cdiv(d.N, TAPS_BN), tm = t.tile / tiles_n, tn = t.tile - tm * tiles_n;
             if (ps.size() > 1) {
                 PartTile pt;
                 pt.dst = reinterpret_cast<float*>(d.D0); pt.dtap = d.dtap; pt.N = d.N; pt.m0 = tm * TAPS_BM; pt.n0 = tn * TAPS_BN;
-                pt.first_slot = nslots; pt.parts = (int)ps.size(); pt.pad = 0;
+                pt.first_slot = nslots; pt.parts = (int)ps.size();
+                pt.rows = d.M - pt.m0 < TAPS_BM ? d.M - pt.m0 : TAPS_BM; pt.cols = d.N - pt.n0 < TAPS_BN ? d.N - pt.n0 : TAPS_BN;
                 parts.push_back(pt);
             }
             for (size_t a2 = 0; a2 < ps.size(); ++a2) {
@@ -3382,7 +3387,7 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
     long long taps_slabs = 0;
     for (int i = 0; i < n; ++i) {
         Resolved r;
-        if (resolve(descs_host + i, false, r) == 0 && wgrad_taps_eligible(r.d)) taps_slabs += (long long)(r.d.M / TAPS_BM) * (r.d.N / TAPS_BN) * (r.d.K / 64);
+        if (resolve(descs_host + i, false, r) == 0 && wgrad_taps_eligible(r.d)) taps_slabs += (long long)cdiv(r.d.M, TAPS_BM) * cdiv(r.d.N, TAPS_BN) * (r.d.K / 64);
     }
     const bool use_taps = taps_slabs >= (long long)min_share * n_cu;
     for (int i = 0; i < n; ++i) {
@@ -3393,7 +3398,7 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         if (use_taps && wgrad_taps_eligible(r.d)) {             // all nine taps per work item: cut into per-CU shares below, no split-K slabs
             r.d.splitk = 1;
             ds[(size_t)i] = r.d;
-            const int tiles = (r.d.M / TAPS_BM) * (r.d.N / TAPS_BN);
+            const int tiles = cdiv(r.d.M, TAPS_BM) * cdiv(r.d.N, TAPS_BN);
             for (int tl = 0; tl < tiles; ++tl) taps_tiles.push_back(TapsTile{i, tl, r.d.K / 64});
             continue;
         }
@@ -3402,8 +3407,11 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         const int BK = 64, sk = d.splitk < 1 ? 1 : d.splitk;
         const int chunk = ((d.K + sk - 1) / sk + BK - 1) / BK * BK;
         // tile: 256 x 128 where the filter has >= 256 output channels (a multiple of 256) and the reduction is long
-        const int tile_kind = !r.big ? 0 : (d.M % 256 == 0 && d.N >= 128 ? 2 : 1);
-        const int tiles_i = tile_kind == 2 ? (d.M / 256) * cdiv(d.N, 128) : (int)r.tiles;
+        // (short reductions -- the 4x4 maps: 8 slabs -- take 64x64 tiles when a layer has to fill the chip on its own; in the static
+        //  queues of a nine-tap group the big tiles' 2.7x fewer cycles per flop count instead)
+        const bool big = r.big || (use_taps && d.M >= 128 && d.N >= 128 && sk == 1);
+        const int tile_kind = !big ? 0 : (d.M % 256 == 0 && d.N >= 128 ? 2 : 1);
+        const int tiles_i = tile_kind == 2 ? (d.M / 256) * cdiv(d.N, 128) : tile_kind == 1 ? cdiv(d.M, 128) * cdiv(d.N, 128) : (int)r.tiles;
         const int n_local = tiles_i * r.zouter * sk;
         for (int it = 0; it < n_local; ++it) {
             const int ks = it / (tiles_i * r.zouter);

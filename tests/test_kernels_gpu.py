@@ -512,7 +512,8 @@ def test_grouped_weight_gradients_match_self_contained_ones():
               # all nine taps in one pass (wgrad_taps_body: 128 | Cout, 64 | Cin, maps 8 / 16 / 32 wide): concat, folded upsample,
               # two output-channel tiles, tiles cut over several CUs (partial slots + tile_parts_reduce_kernel)
               (4, 8, 64, 64, 128, 1, 0), (4, 16, 64, 64, 128, 1, 0), (2, 16, 128, 0, 128, 1, 1), (4, 4, 64, 0, 128, 1, 1),
-              (2, 32, 64, 0, 256, 1, 0)]
+              (2, 32, 64, 0, 256, 1, 0),
+              (4, 16, 8, 0, 128, 1, 0), (4, 16, 128, 0, 8, 1, 0)]          # the 8-channel ends of the net: one partly filled tile
     jobs = []
     for rep in range(240):
         N, H, C0, C1, Cout, stride, ups = shapes[rep % len(shapes)]
