@@ -146,8 +146,16 @@ int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G);
  *                             *need_bytes_out = bytes dev_buf must hold; with dev_buf == NULL or too small nothing is
  *                             built (*handle_out = NULL, return 0): call once to size, once to build.  Synchronous
  *                             (hipMemcpy): call it outside stream capture.
- *   mdm_wgrad_group_launch    the two launches, stream-ordered and capturable.  D0 = (acc0 ? D0 : 0) + dW.
+ *   mdm_wgrad_group_launch    the launches of the group, stream-ordered and capturable.  D0 = (acc0 ? D0 : 0) + dW.
  *   mdm_wgrad_group_destroy   frees the host-side handle (not dev_buf).
+ * Nine-tap form (round 3).  3x3 stride-1 members (maps 8 / 16 / 32 wide, overwrite form) whose group gives every CU a share
+ * of >= MDM_TAPS_MIN_SHARE (default 48) 64-pixel slabs run all nine taps in one pass over dY and the input (wgrad_taps_body):
+ * the group is then ONE persistent launch of one workgroup per CU walking its column of the item table -- equal contiguous
+ * shares of the (tile, slab) space, the remaining per-tap items in the same queues -- plus the split-K sum of per-tap layers
+ * and tile_parts_reduce_kernel, which adds the fp32 partial slots of the tiles a share boundary cut.  The slots live in
+ * dev_buf too (they are part of *need_bytes_out: ~80 MB for the whole cfg2 backward), descriptor.splitk / ws of such a member
+ * are ignored.  Same results as the per-tap form up to fp32 summation order.  Environment: MDM_WGRAD_TAPS=0 keeps every layer
+ * on the per-tap kernels; MDM_TAPS_DEBUG=1 prints the schedule of each group.
  * ------------------------------------------------------------------------- */
 int mdm_wgrad_group_accepts(const mdm_gemm_desc* desc_host);
 int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, void* dev_buf, int64_t dev_bytes,
