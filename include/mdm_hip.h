@@ -113,6 +113,12 @@ typedef struct mdm_gemm_desc {
      * NULL gnf_out = plain epilogue. */
     void* gnf_out; const float* gnf_gamma; const float* gnf_beta; float* gnf_stats;
     int32_t gnf_G, gnf_silu; float gnf_eps; int32_t _p4;
+    /* dtype MDM_F32, optional: the filters of B once more, written by mdm_split_shadow (same offsets and leading dimension as B).
+     * With it, a 3x3 stride-1 forward convolution that qualifies for the halo kernel multiplies on the bf16 matrix pipe with fp32
+     * storage and fp32 accumulation: every operand x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), a product = hi*hi + hi*lo + lo*hi
+     * -- relative error <= ~2^-16 per product instead of 2^-24, at a fifth of the matrix time of the exact path.  Descriptors that do
+     * not qualify ignore it and run the exact fp32 path on B.  NULL = exact fp32 everywhere (the parity path). */
+    const void* B_split;
 } mdm_gemm_desc;
 
 int mdm_gemm(const mdm_gemm_desc* desc_host, void* stream);
@@ -372,6 +378,13 @@ int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  * for every 64x64 tile listed in `tiles` (device, int64 x5 per tile: element offset of one tap's [Cout][Cin] matrix, Cout,
  * Cin, row0, col0; Cout % 8 == Cin % 8 == 0) write PT[off + c*Cout + r] = Pb[off + r*Cin + c]. */
 int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, int ntiles, void* stream);
+/* The B_split shadow of fp32 filters (mdm_gemm_desc.B_split): for each of the `nseg` segments (off, len) of the device table `segs`
+ * (element offsets into P / Ps; off % 4 == 0, len % 32 == 0; a segment is a run of filter rows whose length is a multiple of 32),
+ * every 32-element block b of the segment becomes 128 bytes at the same offset of Ps: 16-byte chunk g (g = 0..3) = the bf16 hi halves
+ * of elements {4g..4g+3, 16+4g..16+4g+3} of the block, chunk 4+g = their bf16 lo halves (hi = bf16(x), lo = bf16(x - hi), both
+ * round-to-nearest-even) -- the arrangement the split halo kernel makes of its input rows in LDS.  Replaces nothing upstream: it is
+ * how the fp32 `F.conv2d` of unet6.py:232-235 reaches the bf16 MFMA pipe at ~fp32 accuracy. */
+int mdm_split_shadow(const float* P, float* Ps, const int64_t* segs, int nseg, void* stream);
 int mdm_fill_f32(float* p, float v, int64_t n, void* stream);
 /* base[off .. off + len) = v for nseg segments segs[i] = {off, len} (device, int64 pairs; len % 4 == 0, len <= 4096, off % 4 == 0):
  * the per-step zeroing of the ACCUMULATED gradient slots only (biases, GroupNorm scales: `optimizer.zero_grad()` at

@@ -2451,12 +2451,43 @@ __device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const float4
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
             }
 }
+// fp32 operands as bf16 pairs (SPLIT, below): x = hi + lo, a fragment register holds 8 hi (or 8 lo) halves of the same 8 k
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4& v) { return __builtin_bit_cast(bf16x8, v); }
+template <int MI, int NI>
+__device__ __forceinline__ void halo_mma_split(f32x4 (&acc)[MI][NI], const float4 (&b)[NI], const float4 (&a)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b[j]), as_bf16x8(a[i]), acc[i][j], 0, 0, 0);
+}
+// One 16-byte chunk pair (8 fp32 values: chunks c and c ^ 4 of a 128-byte row) -> 8 bf16 hi halves in the first chunk, 8 bf16 lo halves
+// in the second, both round-to-nearest: hi = bf16(x), lo = bf16(x - hi) (the difference is exact in fp32), |x - hi - lo| <= 2^-16 |x|.
+__device__ __forceinline__ void split_bf16_pair(float4& a, float4& b) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bf16_t h0 = f2bf(x[2 * k]), h1 = f2bf(x[2 * k + 1]);
+        h[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        l[k] = (uint32_t)f2bf(x[2 * k] - bf2f(h0)) | ((uint32_t)f2bf(x[2 * k + 1] - bf2f(h1)) << 16);
+    }
+    a = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
+    b = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
+}
 // T = bf16_t: v_mfma_f32_16x16x32_bf16 on 64-channel slabs.  T = float (the exact-fp32 path: the reverse sampler of record): the SAME
 // tile, halo, ring and offset tables in bytes -- a 128-byte halo row is then 32 channels, a lane's 16-byte fragment is 4 consecutive
 // k that feed four v_mfma_f32_16x16x4_f32 (lane group g supplies k = 4 g + j to MFMA j on both operands, as in gemm_f32_mfma_kernel).
 // At a sixteenth of the bf16 matrix rate the loop, not the prologue / epilogue / LDS, sets the time: the kernel is MFMA-bound.
-template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t>
+// SPLIT (T = float only; the descriptor's B_split): fp32 storage, products on the bf16 matrix pipe.  Every operand is x = hi + lo with
+// hi = bf16(x), lo = bf16(x - hi), and a product is hi*hi + hi*lo + lo*hi (the lo*lo term, <= 2^-16 of the product, is dropped):
+// three v_mfma_f32_16x16x32_bf16 (48 matrix cycles per 32 k) instead of eight v_mfma_f32_16x16x4_f32 (256), fp32 accumulation.
+// An earlier build split every fragment in registers per wave and tap and was VALU-bound (DESIGN finding 28); here the halo of a
+// channel slab is split ONCE, IN PLACE in LDS by all 512 threads during the last filter row of the slab in front of it (chunk g of a
+// 128-byte row becomes the 8 hi halves, chunk g ^ 4 the 8 lo halves of the same 8 channels: the fragment addresses do not change),
+// and the filter tiles arrive already split from the B_split shadow (mdm_split_shadow: same bytes, same arrangement).
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t, bool SPLIT = false>
 __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
+    static_assert(!SPLIT || sizeof(T) == 4, "conv_halo: SPLIT is the fp32-storage variant");
     constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
     constexpr int NG = 9 / TG;                                    // groups per channel slab
     constexpr int D = TG == 1 ? (NSB == 4 ? 3 : NSB - 2) : NSB - 1;  // refill distance (groups)
@@ -2464,6 +2495,10 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     static_assert(9 % TG == 0 && D >= 1 && D < NG && APT * (NG - D) >= NPW, "conv_halo: halo pieces do not fit in front of the refill distance");
     static_assert(MI >= 1 && NI >= 1, "conv_halo: tile too small for 4 x 2 waves");
     constexpr int B_BYTES = BN * 128, STAGE_B = TG * B_BYTES;
+    // DMA operations a wave issues behind the last halo piece of a slab up to the barrier of the slab's last group: the filter
+    // tiles of the groups in between (the pieces go out in groups 0 .. (NPW - 1) / APT, behind that group's own filter tiles)
+    constexpr int SPLIT_WAIT = (NG - 2 - (NPW - 1) / APT) * TG;
+    static_assert(!SPLIT || (SPLIT_WAIT >= 0 && SPLIT_WAIT <= halo_vmcnt<NPW, APT, D, TG>(NG - 1)), "conv_halo: split schedule");
     constexpr int KC = 128 / (int)sizeof(T);                    // channels per slab (one 128-byte halo row)
     constexpr bool F32 = sizeof(T) == 4;
     typedef typename std::conditional<F32, float4, bf16x8>::type Frag;
@@ -2522,7 +2557,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     // issue into the dummy page so that every wave counts the same number of DMA operations)
     const bool b_wave = wave * 8 < BN;
     const int bn = n0 + (b_wave ? wave * 8 : 0) + (lane >> 3);
-    const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const T*>(d.B) + (int64_t)bn * d.ldb) + lch16;
+    const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const T*>(SPLIT ? d.B_split : d.B) + (int64_t)bn * d.ldb) + lch16;
     auto issue_b = [&](int tap, int cs, int lds_off) {               // lds_off: byte offset of the tile inside the ring
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * KC) * (int64_t)sizeof(T);
         lds_dma16((cs < NCS && b_wave) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
@@ -2566,6 +2601,24 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // SPLIT: halo rows [0, HR) of `abuf` from fp32 to (hi, lo) bf16 halves in place; item = (row, chunk pair g / g ^ 4), one thread each
+    auto split_halo = [&](char* abuf) {
+        for (int id = t; id < HR * 4; id += NW * 64) {
+            const int hr = id >> 2, pg = ((id & 3) ^ hr) & 7;          // chunk c of row hr sits at position c ^ (hr & 7)
+            float4* pa = reinterpret_cast<float4*>(abuf + hr * 128 + (pg << 4));           // chunk g:     k = 4 g .. 4 g + 3
+            float4* pb = reinterpret_cast<float4*>(abuf + hr * 128 + ((pg ^ 4) << 4));     // chunk g + 4: k = 16 + 4 g ..
+            float4 va = *pa, vb = *pb;
+            split_bf16_pair(va, vb);
+            *pa = va;                                                  // 8 hi halves: what the k-step-0 fragment address reads
+            *pb = vb;                                                  // 8 lo halves: k-step 1
+        }
+    };
+    if constexpr (SPLIT) {                 // slab 0: its pieces are older than the D * TG filter tiles of the prologue
+        wait_vmcnt<D * TG>();
+        __builtin_amdgcn_s_barrier();
+        split_halo(lds);
+    }
+
     int a_cur = 0;                         // byte offset of the halo buffer being multiplied
     int b_stage = 0;                       // ring stage of the current tap-slab
     const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
@@ -2573,7 +2626,12 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     {                                                                                                            \
         if ((T) % TG == 0) {                                                                                     \
             /* the filter tiles of this group have landed (issued D groups ago), and everything older */         \
-            wait_vmcnt<halo_vmcnt<NPW, APT, D, TG>((T) / TG)>();                                                 \
+            /* SPLIT: behind the barrier of the LAST group the whole halo of the next slab must have landed too   \
+               (SPLIT_WAIT: what was issued behind its last piece), so that it can be split during this group;    \
+               the split's LDS writes are complete before the barrier that opens the next slab */                 \
+            if (SPLIT && (T) / TG == NG - 1) wait_vmcnt<SPLIT_WAIT>();                                           \
+            else wait_vmcnt<halo_vmcnt<NPW, APT, D, TG>((T) / TG)>();                                            \
+            if (SPLIT && (T) == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            \
             __builtin_amdgcn_s_barrier();                                                                        \
             const int rs = b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D;                                 \
             /* (dealing these DMA pieces out between the MFMAs of the tap, as conv_lin2 does, changed neither the  \
@@ -2582,6 +2640,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
                 issue_b((((T) / TG + D) % NG) * TG + k, cs + ((T) / TG + D) / NG, rs * STAGE_B + k * B_BYTES);   \
             _Pragma("unroll") for (int q = 0; q < APT; ++q)                                                      \
                 if (((T) / TG) * APT + q < NPW) issue_a(((T) / TG) * APT + q, cs + 1, lds + (a_cur ^ a_flip));   \
+            if constexpr (SPLIT) {                                                                               \
+                if ((T) / TG == NG - 1 && cs + 1 < NCS) split_halo(lds + (a_cur ^ a_flip));                      \
+            }                                                                                                    \
         }                                                                                                        \
         const char* As = lds + a_cur;                                                                            \
         const char* Bs = bring + b_stage * STAGE_B + ((T) % TG) * B_BYTES;                                       \
@@ -2594,13 +2655,17 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
                     afr[0][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[0][i] ^ (ks << 6)));             \
         }                                                                                                        \
-        halo_mma_tile<MI, NI>(acc, bfr[0], afr[(T) & 1][0]);                                                     \
+        if constexpr (SPLIT) halo_mma_split<MI, NI>(acc, bfr[0], afr[(T) & 1][1]);      /* b.hi x a.lo */       \
+        else halo_mma_tile<MI, NI>(acc, bfr[0], afr[(T) & 1][0]);                                                \
         if ((T) < 8) {             /* the next tap reads the SAME halo buffer at shifted rows: fetch it now */    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
                     afr[((T) + 1) & 1][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[((T) + 1) % 9][i] ^ (ks << 6))); \
         }                                                                                                        \
-        halo_mma_tile<MI, NI>(acc, bfr[1], afr[(T) & 1][1]);                                                     \
+        if constexpr (SPLIT) {                                                                                   \
+            halo_mma_split<MI, NI>(acc, bfr[1], afr[(T) & 1][0]);                       /* b.lo x a.hi */       \
+            halo_mma_split<MI, NI>(acc, bfr[0], afr[(T) & 1][0]);                       /* b.hi x a.hi */       \
+        } else halo_mma_tile<MI, NI>(acc, bfr[1], afr[(T) & 1][1]);                                              \
         if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
     Frag afr[2][2][MI];                    // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
@@ -2634,10 +2699,10 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 #endif
 }
 
-template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t>
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t, bool SPLIT = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    conv_halo_body<BM, NPW, BN, NSB, TG, T>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+    conv_halo_body<BM, NPW, BN, NSB, TG, T, SPLIT>(d, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ----------------------------------------------------------------------------
@@ -2836,7 +2901,7 @@ static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of on
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW, int NSB, int BN = 64, typename T = bf16_t>
+template <int BM, int NPW, int NSB, int BN = 64, typename T = bf16_t, bool SPLIT = false>
 static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filter row (3 taps) per barrier
     constexpr int TG = 3;
     const int NPA = halo_pieces(BM, d.OH, d.OW);
@@ -2846,12 +2911,12 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filt
     MDM_REQUIRE(NPA <= 8 * NPW && bytes <= 160 * 1024, "conv_halo: tile does not fit (NPA=%d, %d bytes)", NPA, bytes);
     static int configured = 0;
     if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN, NSB, TG, T>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BM, NPW, BN, NSB, TG, T, SPLIT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
     dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / BN)));
-    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T>), grid, dim3(512), bytes, s, d);
+    hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T, SPLIT>), grid, dim3(512), bytes, s, d);
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
@@ -3097,6 +3162,15 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     } else if (const int hb32 = halo_tile_f32(d)) {
         // exact-fp32 3x3 convolutions on the halo kernel (forward, folded upsample, transposed shadow): MFMA-bound
         const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
+        if (d.B_split != nullptr && !d.transposed) {
+            // fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (conv_halo_body<..., SPLIT>)
+            if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, 2, 64, float, true>(d, s) : launch_halo<256, 6, 2, 64, float, true>(d, s);
+            else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float, true>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float, true>(d, s)
+                                                                                             : launch_halo<128, 6, 3, 64, float, true>(d, s);
+            else if ((int64_t)(d.M / 64) * (d.N / 64) < kBigMinTiles && d.N % 32 == 0)
+                rc = npw <= 2 ? launch_halo<64, 2, 3, 32, float, true>(d, s) : launch_halo<64, 3, 3, 32, float, true>(d, s);
+            else rc = npw <= 2 ? launch_halo<64, 2, 3, 64, float, true>(d, s) : launch_halo<64, 3, 3, 64, float, true>(d, s);
+        } else
         if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, 2, 64, float>(d, s) : launch_halo<256, 6, 2, 64, float>(d, s);
         else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float>(d, s)
                                                                                          : launch_halo<128, 6, 3, 64, float>(d, s);

@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256) void transpose_shadow_bf16_kernel(const bf16_t
     }
 }
 
+// The split shadow of fp32 filters (mdm_gemm_desc.B_split; conv_halo_body<..., SPLIT>): per 32-element block, chunk g = 8 bf16 hi
+// halves of elements {4g..4g+3, 16+4g..16+4g+3}, chunk 4+g = their lo halves.  One thread per (block, g): two 16-byte loads, two stores.
+// segs[i] = {element offset, length}; blockIdx.y = segment.
+__global__ __launch_bounds__(256) void split_shadow_kernel(const float* P, float* Ps, const int64_t* segs) {
+    const int64_t off = segs[2 * blockIdx.y], len = segs[2 * blockIdx.y + 1];
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < len / 8; id += (int64_t)gridDim.x * 256) {
+        const int64_t base = off + (id >> 2) * 32 + (id & 3) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(P + base), b = *reinterpret_cast<const float4*>(P + base + 16);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bf16_t h0 = f2bf(x[2 * k]), h1 = f2bf(x[2 * k + 1]);
+            h[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            l[k] = (uint32_t)f2bf(x[2 * k] - bf2f(h0)) | ((uint32_t)f2bf(x[2 * k + 1] - bf2f(h1)) << 16);
+        }
+        *reinterpret_cast<uint4*>(Ps + base) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(Ps + base + 16) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
 }
@@ -135,6 +156,12 @@ extern "C" int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t
     MDM_REQUIRE(Pb && PT && tiles && ntiles > 0, "transpose_shadow_bf16: bad arguments");
     hipLaunchKernelGGL(transpose_shadow_bf16_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Pb, (bf16_t*)PT, tiles, ntiles);
     return launch_status("transpose_shadow_bf16");
+}
+extern "C" int mdm_split_shadow(const float* P, float* Ps, const int64_t* segs, int nseg, void* stream) {
+    MDM_REQUIRE(P && Ps && segs && nseg > 0 && nseg <= 65535, "split_shadow: bad arguments");
+    MDM_REQUIRE((((uintptr_t)P | (uintptr_t)Ps) & 15) == 0, "split_shadow: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(split_shadow_kernel, dim3(64, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, P, Ps, segs);
+    return launch_status("split_shadow");
 }
 extern "C" int mdm_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ogrid(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);

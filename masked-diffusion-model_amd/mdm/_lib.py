@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("gnb_x", vp), ("gnb_stats", vp), ("gnb_gamma", vp), ("gnb_beta", vp), ("gnb_dgamma", vp), ("gnb_dbeta", vp),
         ("gnb_sum_img", vp), ("gnb_sum_all", vp), ("gnb_G", i32), ("gnb_silu", i32), ("gnb_sum_ld", i32), ("_p3", i32), ("gnb_add", vp),
         ("gnf_out", vp), ("gnf_gamma", vp), ("gnf_beta", vp), ("gnf_stats", vp), ("gnf_G", i32), ("gnf_silu", i32), ("gnf_eps", f32), ("_p4", i32),
+        ("B_split", vp),
     ]
 
 
@@ -92,6 +93,7 @@ _PROTOS = {
     "mdm_adamw_ema": ([vp, vp, vp, vp, vp, vp, i64, vp, vp, f32, f32, vp], i32),
     "mdm_cast_bf16": ([vp, vp, i64, vp], i32),
     "mdm_transpose_shadow_bf16": ([vp, vp, vp, i32, vp], i32),
+    "mdm_split_shadow": ([vp, vp, vp, i32, vp], i32),
     "mdm_fill_f32": ([vp, f32, i64, vp], i32),
     "mdm_fill_segments_f32": ([vp, vp, i32, f32, vp], i32),
     "mdm_graph_begin": ([vp], i32),

@@ -64,6 +64,7 @@ class AdamW:
         call("mdm_adamw_ema", ptr(st.P), ptr(st.G), ptr(self.m), ptr(self.v), ptr(ema_buf), ptr(st.Pb), st.size,
              ptr(self.hp), ptr(self.sqnorm), float(max_norm), float(gmul), stream())
         st.emit_transposed_shadow()
+        st.emit_split_shadow()          # fp32 stores with split products: the filters' hi / lo shadow follows the weights
 
     def step(self, max_norm=0.0):
         self.hyper()

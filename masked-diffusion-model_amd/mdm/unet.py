@@ -114,6 +114,28 @@ class ParamStore:
         taps, co, ci = e.ishape
         return self.PbT[e.off:e.off + e.n].view(taps, ci, co)
 
+    # -- fp32 stores: the filters once more as bf16 hi / lo pairs (mdm_gemm_desc.B_split, conv_halo_body<..., SPLIT>)
+    def enable_split(self):
+        """Allocate the split shadow `Ps` (same offsets as P) for every conv filter whose rows are whole 32-channel blocks."""
+        if getattr(self, "Ps", None) is not None:
+            return
+        assert self.dtype == F32, "the split shadow belongs to an fp32 store"
+        segs = [(e.off, e.n) for e in self.entries.values() if e.kind in ("conv", "convlin") and e.ishape[2] % 32 == 0]
+        self.Ps = torch.zeros(self.size, device=self.device, dtype=torch.float32)
+        self.split_segs = torch.tensor(segs, dtype=torch.int64, device=self.device)
+        self.emit_split_shadow()
+
+    def emit_split_shadow(self):
+        if getattr(self, "Ps", None) is not None:
+            _lib.call("mdm_split_shadow", _lib.ptr(self.P), _lib.ptr(self.Ps), _lib.ptr(self.split_segs),
+                      int(self.split_segs.shape[0]), _lib.stream())
+
+    def w_split(self, name):
+        e = self.entries[name]
+        if getattr(self, "Ps", None) is None or e.kind not in ("conv", "convlin") or e.ishape[2] % 32:
+            return None
+        return self.Ps[e.off:e.off + e.n].view(e.ishape)
+
     def emit_transposed_shadow(self):
         if self.PbT is not None:
             # from the bf16 shadow the optimizer (or sync_shadow's cast) has just written: a third less traffic than from P
@@ -124,6 +146,7 @@ class ParamStore:
         if self.Pb is not None:
             ops.cast_bf16(self.P, self.Pb)
             self.emit_transposed_shadow()
+        self.emit_split_shadow()
 
     # -- reference state_dict interchange
     def to_internal(self, name, t):
@@ -208,7 +231,8 @@ class _Conv:
             rv, ld = n.T_all[:, self.fc_slot:], n.fc_total
         return ops.conv_fwd_fields(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
                                    st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
-                                   resid=self.resid.data if self.resid else None, ws=n.splitk_ws)
+                                   resid=self.resid.data if self.resid else None, ws=n.splitk_ws,
+                                   w_split=st.w_split(self.name + ".weight") if n.split_products else None)
 
     def fwd(self):
         n = self.net
@@ -480,7 +504,7 @@ class UNet:
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
     def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True,
-                 group_wgrads=True, wgrad_group_bytes=None, pair_convs=True, _dry=False):
+                 group_wgrads=True, wgrad_group_bytes=None, pair_convs=True, f32_products="exact", _dry=False):
         if _dry:       # shape/parameter bookkeeping only (no device, no kernels): see `param_table`
             self.cfg, self.N, self.H, self.W, self.dt = dict(cfg), N, H, W, dtype
             self.store = ParamStore()
@@ -503,6 +527,10 @@ class UNet:
         self.use_graph = use_graph
         self.group_wgrads = group_wgrads            # weight gradients of the bf16 path run as grouped launches
         self.pair_convs = dtype == BF16 and pair_convs   # skip projections share a launch with conv1 / conv2's data gradient
+        # fp32 storage with the FORWARD 3x3 convolutions' products on the bf16 matrix pipe as hi / lo pairs (~2^-16 per product
+        # instead of 2^-24; mdm_gemm_desc.B_split).  "exact" (default) is the parity path; "split" is for the reverse sampler.
+        assert f32_products in ("exact", "split") and (f32_products == "exact" or dtype == F32), f32_products
+        self.split_products = f32_products == "split"
         if wgrad_group_bytes is None:
             # A group is one launch AND one gradient bucket (mdm/dist.py).  Under data parallelism ~32 MB groups let the exchange of one
             # bucket run under the backward of the next; a single process has nothing to exchange, and there one group over the whole
@@ -520,6 +548,8 @@ class UNet:
             self.store.allocate(self.device, dtype)
         else:
             assert store.dtype == dtype, "a shared parameter store must have the same compute dtype"
+        if self.split_products:
+            self.store.enable_split()
         self._set_param_marks()
         self._materialize()
         if not shared:
@@ -547,7 +577,8 @@ class UNet:
             return self
         plans = self.__dict__.setdefault("_batch_plans", {})
         if N not in plans:
-            plans[N] = UNet(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph)
+            plans[N] = UNet(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph,
+                            f32_products="split" if self.split_products else "exact")
         return plans[N]
 
     # ---- construction ---------------------------------------------------------

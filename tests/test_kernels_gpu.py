@@ -210,6 +210,70 @@ def test_conv_halo_forward_and_data_gradient(case):
         assert _relerr(d1, want[..., C0:]) < _tol(dt, 1.5)
 
 
+def _split_shadow(w_tap):
+    """mdm_split_shadow over one filter tensor [tap][Cout][Cin] (Cin % 32 == 0) -> the B_split operand."""
+    from mdm import _lib
+    P = w_tap.to(_dev(), torch.float32).contiguous()
+    Ps = torch.full_like(P, float("nan"))
+    segs = torch.tensor([[0, P.numel()]], dtype=torch.int64, device=_dev())
+    _lib.call("mdm_split_shadow", _lib.ptr(P), _lib.ptr(Ps), _lib.ptr(segs), 1, _lib.stream())
+    return P, Ps
+
+
+def test_split_shadow_layout():
+    """mdm_split_shadow: per 32-element block, chunk g = bf16(x) of elements {4g..4g+3, 16+4g..16+4g+3}, chunk 4+g = bf16(x - hi);
+    hi + lo reproduces x to 2^-16."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(2, 8, 64, generator=g) * torch.logspace(-6, 3, 64)
+    P, Ps = _split_shadow(w)
+    torch.cuda.synchronize()
+    halves = Ps.cpu().view(torch.int16).view(-1, 8, 8)               # [block][chunk][8 halves]
+    x = w.reshape(-1, 32)
+    idx = torch.tensor([[4 * gq + j if j < 4 else 16 + 4 * gq + j - 4 for j in range(8)] for gq in range(4)])
+    xs = x[:, idx]                                                   # [block][g][8]
+    hi = halves[:, :4].view(torch.bfloat16).float()
+    lo = halves[:, 4:].view(torch.bfloat16).float()
+    assert torch.equal(hi, xs.bfloat16().float())
+    assert torch.equal(lo, (xs - hi).bfloat16().float())
+    assert float(((hi + lo) - xs).abs().max() / xs.abs().max()) < 2.0 ** -16 and torch.all(((hi + lo) - xs).abs() <= xs.abs() * 2.0 ** -16)
+
+
+@pytest.mark.parametrize("case", [(32, 32, 128, 0, 128, 0), (100, 32, 128, 0, 128, 0), (25, 16, 64, 64, 256, 0), (8, 64, 32, 0, 64, 0),
+                                  (8, 8, 128, 0, 128, 0), (16, 4, 64, 64, 256, 0), (4, 4, 512, 0, 512, 0),
+                                  (8, 8, 96, 0, 128, 1), (12, 16, 256, 0, 128, 1)])
+def test_conv_halo_split_products(case):
+    """fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (mdm_gemm_desc.B_split, conv_halo_body<..., SPLIT>): every
+    halo tile shape, two sources, folded upsample, the sampler's 100-image batch.  Against an fp64 convolution the split path must stay
+    within 2e-5 (measured ~2e-6; the exact fp32 path ~1e-7, bf16 ~3e-3) -- and it must actually differ from the exact path, i.e. run."""
+    from mdm import ops
+    N, H, C0, C1, Cout, ups = case
+    C = C0 + C1
+    g = torch.Generator().manual_seed(N + H + C + ups)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(N, Cout, generator=g)
+    HO = H << ups
+    res = torch.randn(N, Cout, HO, HO, generator=g)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    y = (F.conv2d(xin.double(), w.double(), b.double(), padding=1) + rv.double()[:, :, None, None] + res.double()).float()
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, ups=ups)
+    xh = _nhwc(x)
+    s0 = xh[..., :C0].contiguous().to(_dev())
+    s1 = xh[..., C0:].contiguous().to(_dev()) if C1 else None
+    P, Ps = _split_shadow(_w_tap(w))
+    outs = {}
+    for tag, wsplit in (("exact", None), ("split", Ps)):
+        out = torch.full((N, HO, HO, Cout), float("nan"), device=_dev())
+        ops.conv_fwd(0, geom, s0, s1, P, b.to(_dev()), out, rowvec=rv.to(_dev()), rv_ld=Cout, resid=_nhwc(res).to(_dev()), w_split=wsplit)
+        torch.cuda.synchronize()
+        outs[tag] = out
+    e_exact, e_split = _relerr(outs["exact"], _nhwc(y)), _relerr(outs["split"], _nhwc(y))
+    assert e_exact < 1e-6, e_exact
+    assert e_split < 2e-5, e_split
+    assert not torch.equal(outs["exact"], outs["split"]), "B_split was ignored: the split kernel did not run"
+
+
 def test_conv_tap_split_with_epilogue():
     """Small-M 3x3 conv: reduction split over the filter taps (slabs + epilogue kernel), full epilogue."""
     from mdm import ops
