@@ -61,7 +61,8 @@ typedef struct mdm_gemm_desc {
     int32_t M, N, K;
     int32_t batch;              /* >= 1; blockIdx.z when conv == 0 */
     int64_t sA, sB, sD, sR;     /* batch strides in elements */
-    const void* A; int32_t lda; int32_t _p0;
+    const void* A; int32_t lda;
+    int32_t f32_split;          /* dtype MDM_F32, layout 0: 1 = the register-staged fp32 kernel may multiply as bf16 hi / lo pairs (see B_split) */
     const void* B; int32_t ldb; int32_t _p1;
     /* implicit-GEMM gather */
     int32_t conv;

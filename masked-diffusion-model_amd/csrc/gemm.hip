@@ -315,8 +315,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(mdm_gemm_desc d) {
 // Shares every index function (gather, split-K ranges, epilogue) with the bf16 kernels.  (It replaced a 64x64x16
 // VALU kernel -- 4x4 fmaf per thread -- that ran the 1000-step fp32 sampler in 28.2 s; this one takes 17.5 s.)
 // ----------------------------------------------------------------------------
-template <int BM, int BN, int LAYOUT>
+// SPLIT (layout 0; mdm_gemm_desc.f32_split): the operands pass through registers on their way into LDS, so each thread splits its own
+// float4 there -- x = hi + lo, hi = bf16(x), lo = bf16(x - hi) -- and stores 4 hi halves at byte 2 k and 4 lo halves at byte 64 + 2 k of
+// the same 128-byte row; a lane group's fragment is then 8 consecutive k of hi (or lo) and a 32-deep slab is THREE
+// v_mfma_f32_16x16x32_bf16 (hi*lo, lo*hi, hi*hi; fp32 accumulate) instead of eight v_mfma_f32_16x16x4_f32: 48 matrix cycles against 256.
+template <int BM, int BN, int LAYOUT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
+    static_assert(!SPLIT || LAYOUT == 0, "gemm_f32_mfma: split products need both operands k-contiguous");
     constexpr int BK = 32, LD = BK + 4;
     constexpr bool A_ROWS = (LAYOUT != 2), B_ROWS = (LAYOUT == 0);
     constexpr int A_EL = BM * LD, B_EL = BN * LD, STAGE = A_EL + B_EL;
@@ -408,6 +413,24 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
     auto store_tiles = [&](int buf) {
         float* As = fsm + buf * STAGE;
         float* Bs = As + A_EL;
+        if constexpr (SPLIT) {
+            auto put = [&](float* row, const float4& v) {          // 4 consecutive k -> 4 hi halves | 4 lo halves
+                const bf16_t h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
+                uint2 hi, lo;
+                hi.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                hi.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                lo.x = (uint32_t)f2bf(v.x - bf2f(h0)) | ((uint32_t)f2bf(v.y - bf2f(h1)) << 16);
+                lo.y = (uint32_t)f2bf(v.z - bf2f(h2)) | ((uint32_t)f2bf(v.w - bf2f(h3)) << 16);
+                char* p = reinterpret_cast<char*>(row) + rk * 2;
+                *reinterpret_cast<uint2*>(p) = hi;
+                *reinterpret_cast<uint2*>(p + 64) = lo;
+            };
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) put(&As[(rr + 32 * i) * LD], ra[i]);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) put(&Bs[(rr + 32 * i) * LD], rb[i]);
+            return;
+        }
         if (A_ROWS) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) *reinterpret_cast<float4*>(&As[(rr + 32 * i) * LD + rk]) = ra[i];
@@ -452,6 +475,33 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
         if (it + 2 < nk) load_tiles(z.kbeg + (it + 2) * BK);
         const float* As = fsm + cur * STAGE;
         const float* Bs = As + A_EL;
+        if constexpr (SPLIT) {
+            bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const char* p = reinterpret_cast<const char*>(&As[(wr * WM + i * 16 + frow) * LD]) + fk * 4;     // 16 (lane >> 4) bytes
+                ah[i] = *reinterpret_cast<const bf16x8*>(p);
+                al[i] = *reinterpret_cast<const bf16x8*>(p + 64);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const char* p = reinterpret_cast<const char*>(&Bs[(wc * WN + j * 16 + frow) * LD]) + fk * 4;
+                bh[j] = *reinterpret_cast<const bf16x8*>(p);
+                bl[j] = *reinterpret_cast<const bf16x8*>(p + 64);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             float4 af[MI], bfr[NI];
@@ -469,6 +519,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(mdm_gemm_desc d) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j].z, af[i].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j].w, af[i].w, acc[i][j], 0, 0, 0);
                 }
+        }
         }
         __syncthreads();
     }
@@ -2439,7 +2490,7 @@ __device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const bf16x8
         for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 }
 template <int MI, int NI>
-__device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const float4 (&b)[NI], const float4 (&a)[MI]) {
+__device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const f32x4 (&b)[NI], const f32x4 (&a)[MI]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -2452,9 +2503,9 @@ __device__ __forceinline__ void halo_mma_tile(f32x4 (&acc)[MI][NI], const float4
             }
 }
 // fp32 operands as bf16 pairs (SPLIT, below): x = hi + lo, a fragment register holds 8 hi (or 8 lo) halves of the same 8 k
-__device__ __forceinline__ bf16x8 as_bf16x8(const float4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 as_bf16x8(const f32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 template <int MI, int NI>
-__device__ __forceinline__ void halo_mma_split(f32x4 (&acc)[MI][NI], const float4 (&b)[NI], const float4 (&a)[MI]) {
+__device__ __forceinline__ void halo_mma_split(f32x4 (&acc)[MI][NI], const f32x4 (&b)[NI], const f32x4 (&a)[MI]) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -2462,7 +2513,7 @@ __device__ __forceinline__ void halo_mma_split(f32x4 (&acc)[MI][NI], const float
 }
 // One 16-byte chunk pair (8 fp32 values: chunks c and c ^ 4 of a 128-byte row) -> 8 bf16 hi halves in the first chunk, 8 bf16 lo halves
 // in the second, both round-to-nearest: hi = bf16(x), lo = bf16(x - hi) (the difference is exact in fp32), |x - hi - lo| <= 2^-16 |x|.
-__device__ __forceinline__ void split_bf16_pair(float4& a, float4& b) {
+__device__ __forceinline__ void split_bf16_pair(f32x4& a, f32x4& b) {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t h[4], l[4];
 #pragma unroll
@@ -2471,8 +2522,8 @@ __device__ __forceinline__ void split_bf16_pair(float4& a, float4& b) {
         h[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
         l[k] = (uint32_t)f2bf(x[2 * k] - bf2f(h0)) | ((uint32_t)f2bf(x[2 * k + 1] - bf2f(h1)) << 16);
     }
-    a = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
-    b = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
+    a = (f32x4){__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3])};
+    b = (f32x4){__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3])};
 }
 // T = bf16_t: v_mfma_f32_16x16x32_bf16 on 64-channel slabs.  T = float (the exact-fp32 path: the reverse sampler of record): the SAME
 // tile, halo, ring and offset tables in bytes -- a 128-byte halo row is then 32 channels, a lane's 16-byte fragment is 4 consecutive
@@ -2501,7 +2552,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     static_assert(!SPLIT || (SPLIT_WAIT >= 0 && SPLIT_WAIT <= halo_vmcnt<NPW, APT, D, TG>(NG - 1)), "conv_halo: split schedule");
     constexpr int KC = 128 / (int)sizeof(T);                    // channels per slab (one 128-byte halo row)
     constexpr bool F32 = sizeof(T) == 4;
-    typedef typename std::conditional<F32, float4, bf16x8>::type Frag;
+    typedef typename std::conditional<F32, f32x4, bf16x8>::type Frag;
     MDM_T(const unsigned long long t_entry = stamp_now();)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -2605,9 +2656,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     auto split_halo = [&](char* abuf) {
         for (int id = t; id < HR * 4; id += NW * 64) {
             const int hr = id >> 2, pg = ((id & 3) ^ hr) & 7;          // chunk c of row hr sits at position c ^ (hr & 7)
-            float4* pa = reinterpret_cast<float4*>(abuf + hr * 128 + (pg << 4));           // chunk g:     k = 4 g .. 4 g + 3
-            float4* pb = reinterpret_cast<float4*>(abuf + hr * 128 + ((pg ^ 4) << 4));     // chunk g + 4: k = 16 + 4 g ..
-            float4 va = *pa, vb = *pb;
+            f32x4* pa = reinterpret_cast<f32x4*>(abuf + hr * 128 + (pg << 4));           // chunk g:     k = 4 g .. 4 g + 3
+            f32x4* pb = reinterpret_cast<f32x4*>(abuf + hr * 128 + ((pg ^ 4) << 4));     // chunk g + 4: k = 16 + 4 g ..
+            f32x4 va = *pa, vb = *pb;
             split_bf16_pair(va, vb);
             *pa = va;                                                  // 8 hi halves: what the k-step-0 fragment address reads
             *pb = vb;                                                  // 8 lo halves: k-step 1
@@ -2629,10 +2680,13 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
             /* SPLIT: behind the barrier of the LAST group the whole halo of the next slab must have landed too   \
                (SPLIT_WAIT: what was issued behind its last piece), so that it can be split during this group;    \
                the split's LDS writes are complete before the barrier that opens the next slab */                 \
+            MDM_T(const unsigned long long tw0 = stamp_now();)                                                   \
             if (SPLIT && (T) / TG == NG - 1) wait_vmcnt<SPLIT_WAIT>();                                           \
             else wait_vmcnt<halo_vmcnt<NPW, APT, D, TG>((T) / TG)>();                                            \
             if (SPLIT && (T) == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            \
+            MDM_T(const unsigned long long tw1 = stamp_now(); t_wait += tw1 - tw0;)                              \
             __builtin_amdgcn_s_barrier();                                                                        \
+            MDM_T(t_bar += stamp_now() - tw1;)                                                                   \
             const int rs = b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D;                                 \
             /* (dealing these DMA pieces out between the MFMAs of the tap, as conv_lin2 does, changed neither the  \
                bf16 step -- 3.904 vs 3.908 ms -- nor the fp32 sampler -- 14.38 vs 14.37 s: measured, not kept) */  \
@@ -2641,7 +2695,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
             _Pragma("unroll") for (int q = 0; q < APT; ++q)                                                      \
                 if (((T) / TG) * APT + q < NPW) issue_a(((T) / TG) * APT + q, cs + 1, lds + (a_cur ^ a_flip));   \
             if constexpr (SPLIT) {                                                                               \
+                MDM_T(const unsigned long long ts0 = stamp_now();)                                               \
                 if ((T) / TG == NG - 1 && cs + 1 < NCS) split_halo(lds + (a_cur ^ a_flip));                      \
+                MDM_T(t_split += stamp_now() - ts0;)                                                             \
             }                                                                                                    \
         }                                                                                                        \
         const char* As = lds + a_cur;                                                                            \
@@ -2669,6 +2725,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
         if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
     Frag afr[2][2][MI];                    // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
+    MDM_T(unsigned long long t_wait = 0, t_bar = 0, t_split = 0;)
     MDM_T(const unsigned long long tstart = stamp_now();)
     for (int cs = 0; cs < NCS; ++cs) {
         MDM_HALO_TAP(0) MDM_HALO_TAP(1) MDM_HALO_TAP(2) MDM_HALO_TAP(3) MDM_HALO_TAP(4)
@@ -2692,7 +2749,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
         const unsigned widx = (unsigned)bx * NW + wave;
         if (widx < 4096) {
             unsigned long long* r = g_stamp_buf + widx * 32;
-            r[0] = 0; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = NCS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
+            r[0] = t_wait; r[1] = t_bar; r[2] = t_split; r[3] = 0; r[4] = NCS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
             r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
         }
     }
@@ -2986,22 +3043,22 @@ static bool ring_eligible(const mdm_gemm_desc& d) {
     return d.K % 64 == 0;
 }
 
-template <int BM, int BN, int LAYOUT>
+template <int BM, int BN, int LAYOUT, bool SPLIT = false>
 static int launch_f32_mfma_one(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     constexpr int bytes = 2 * (BM + BN) * 36 * 4;
     static bool configured = false;
     if (!configured) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<BM, BN, LAYOUT>),
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<BM, BN, LAYOUT, SPLIT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, LAYOUT>), grid, dim3(256), bytes, s, d);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, LAYOUT, SPLIT>), grid, dim3(256), bytes, s, d);
     return 0;
 }
 template <int BM, int BN>
 static int launch_f32_mfma(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     switch (d.layout) {
-        case 0: return launch_f32_mfma_one<BM, BN, 0>(d, grid, s);
+        case 0: return d.f32_split ? launch_f32_mfma_one<BM, BN, 0, true>(d, grid, s) : launch_f32_mfma_one<BM, BN, 0>(d, grid, s);
         case 1: return launch_f32_mfma_one<BM, BN, 1>(d, grid, s);
         default: return launch_f32_mfma_one<BM, BN, 2>(d, grid, s);
     }

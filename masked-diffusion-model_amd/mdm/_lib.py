@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
     _fields_ = [
         ("dtype", i32), ("layout", i32), ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
         ("sA", i64), ("sB", i64), ("sD", i64), ("sR", i64),
-        ("A", vp), ("lda", i32), ("_p0", i32),
+        ("A", vp), ("lda", i32), ("f32_split", i32),
         ("B", vp), ("ldb", i32), ("_p1", i32),
         ("conv", i32), ("OH", i32), ("OW", i32), ("IH", i32), ("IW", i32),
         ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32), ("transposed", i32), ("ups", i32),

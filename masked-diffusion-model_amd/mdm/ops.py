@@ -61,11 +61,12 @@ def conv_flops(g: ConvGeom):
     return 2.0 * g.N * g.OH * g.OW * g.Cout * g.Cin * g.taps
 
 
-def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None, gnf=None, w_split=None):
+def conv_fwd(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None, gnf=None, w_split=None,
+             f32_split=0):
     """out[N,OH,OW,Cout] = conv(concat(src0,src1), w[tap][Cout][Cin]) + bias + rowvec[n] + resid.
     Returns the descriptor.  `gnf` = dict(out, gamma, beta, stats, G, silu, eps): also the GroupNorm of the result in the
     same launch (only where conv_fwd_can_fuse_gn says so); `fuse_gn_fwd(desc, ...)` sets it on a RECORDED call afterwards."""
-    return _lib.gemm(**conv_fwd_fields(dt, g, src0, src1, w, bias, out, rowvec, rv_ld, resid, out_f32, ws, gnf, w_split))
+    return _lib.gemm(**conv_fwd_fields(dt, g, src0, src1, w, bias, out, rowvec, rv_ld, resid, out_f32, ws, gnf, w_split, f32_split))
 
 
 def conv_fwd_pair(fields_a, fields_b):
@@ -74,12 +75,15 @@ def conv_fwd_pair(fields_a, fields_b):
 
 
 def conv_fwd_fields(dt, g: ConvGeom, src0, src1, w, bias, out, rowvec=None, rv_ld=0, resid=None, out_f32=0, ws=None, gnf=None,
-                    w_split=None):
+                    w_split=None, f32_split=0):
     """`w_split` (fp32 only): the same filters from the store's split shadow (mdm_split_shadow) -- where the convolution qualifies,
-    its products then run on the bf16 matrix pipe as hi / lo pairs (mdm_gemm_desc.B_split); elsewhere it is ignored."""
+    its products then run on the bf16 matrix pipe as hi / lo pairs (mdm_gemm_desc.B_split); elsewhere it is ignored.  `f32_split`:
+    the same permission for the convolutions that run on the register-staged fp32 kernel (1x1, stride 2, the two ends of the net)."""
     extra = {} if gnf is None else _gnf_fields(gnf)
     if w_split is not None:
         extra["B_split"] = w_split
+    if f32_split:
+        extra["f32_split"] = 1
     return dict(**extra, dtype=dt, layout=0, M=g.N * g.OH * g.OW, N=g.Cout, K=g.taps * g.Cin,
               conv=1, OH=g.OH, OW=g.OW, IH=g.VH, IW=g.VW, KH=g.KH, KW=g.KW, stride=g.stride,
               pad_t=g.pad_t, pad_l=g.pad_l, transposed=0, ups=g.ups, C0=g.C0, C1=g.C1, Ck=g.Cin,

@@ -232,7 +232,8 @@ class _Conv:
         return ops.conv_fwd_fields(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
                                    st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
                                    resid=self.resid.data if self.resid else None, ws=n.splitk_ws,
-                                   w_split=st.w_split(self.name + ".weight") if n.split_products else None)
+                                   w_split=st.w_split(self.name + ".weight") if n.split_products else None,
+                                   f32_split=int(n.split_products))
 
     def fwd(self):
         n = self.net

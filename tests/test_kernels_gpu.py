@@ -274,6 +274,38 @@ def test_conv_halo_split_products(case):
     assert not torch.equal(outs["exact"], outs["split"]), "B_split was ignored: the split kernel did not run"
 
 
+@pytest.mark.parametrize("case", [(100, 16, 256, 0, 128, 1, (0, 0, 0, 0)), (25, 8, 128, 64, 256, 1, (0, 0, 0, 0)), (10, 32, 128, 0, 128, 3, (0, 0, 1, 1)),
+                                  (6, 32, 8, 0, 128, 3, (1, 1, 1, 1)), (6, 32, 128, 0, 8, 3, (1, 1, 1, 1)), (3, 8, 40, 0, 24, 3, (1, 1, 1, 1))])
+def test_f32_split_register_staged(case):
+    """mdm_gemm_desc.f32_split on the convolutions that run on the register-staged fp32 kernel (1x1 incl. two sources, SamePad stride 2,
+    the 8-channel ends of the net, ragged channel counts): products as bf16 hi / lo pairs, within 2e-5 of an fp64 convolution."""
+    from mdm import ops
+    N, H, C0, C1, Cout, K, pads = case
+    C = C0 + C1
+    stride = 2 if pads == (0, 0, 1, 1) else 1
+    g = torch.Generator().manual_seed(N + H + C + Cout)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(Cout, C, K, K, generator=g) / (K * C ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    xp = F.pad(x, (pads[1], pads[3], pads[0], pads[2]))
+    y = F.conv2d(xp.double(), w.double(), b.double(), stride=stride).float()
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, KH=K, KW=K, stride=stride, pad_t=pads[0], pad_l=pads[1], pad_b=pads[2], pad_r=pads[3])
+    xh = _nhwc(x)
+    s0 = xh[..., :C0].contiguous().to(_dev())
+    s1 = xh[..., C0:].contiguous().to(_dev()) if C1 else None
+    P = _w_tap(w).to(_dev())
+    outs = {}
+    for tag, flag in (("exact", 0), ("split", 1)):
+        out = torch.full(tuple(_nhwc(y).shape), float("nan"), device=_dev())
+        ops.conv_fwd(0, geom, s0, s1, P, b.to(_dev()), out, f32_split=flag)
+        torch.cuda.synchronize()
+        outs[tag] = out
+    e_exact, e_split = _relerr(outs["exact"], _nhwc(y)), _relerr(outs["split"], _nhwc(y))
+    assert e_exact < 1e-6, e_exact
+    assert e_split < 2e-5, e_split
+    assert not torch.equal(outs["exact"], outs["split"]), "f32_split was ignored"
+
+
 def test_conv_tap_split_with_epilogue():
     """Small-M 3x3 conv: reduction split over the filter taps (slabs + epilogue kernel), full epilogue."""
     from mdm import ops
