@@ -2162,8 +2162,12 @@ __device__ __forceinline__ void wgrad_taps_body(const mdm_gemm_desc& d, const in
     const int xld = xs1 ? d.ld1 : d.ld0;
     const bf16_t* const xS = reinterpret_cast<const bf16_t*>(xs1 ? d.src1 : d.src0) + (xs1 ? xgn - d.C0 : xgn);
     const int ups = d.ups;
+    // (`d` lives in device memory and the loop is full of asm with memory clobbers: a `d.N` inside x_src was RE-LOADED in every iteration,
+    //  and the s_waitcnt vmcnt(0) the compiler puts behind such a load also waits for every LDS-DMA in flight -- the prefetch ring of the
+    //  loop was drained once per slab.  Everything the loop needs from the descriptor is a local.)
+    const bool x_live = xgn < d.N;
     auto x_src = [&](int blk) -> const char* {                    // where block `blk` (pixels 64 blk ..) comes from
-        if (blk < 0 || blk >= total_slabs || blk > k1 || xgn >= d.N) return zlane;
+        if (blk < 0 || blk >= total_slabs || blk > k1 || !x_live) return zlane;
         const int p = blk * 64 + xrow;
         int phys = p;
         if (ups) {
