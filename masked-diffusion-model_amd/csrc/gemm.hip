@@ -2658,14 +2658,24 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 
     // SPLIT: halo rows [0, HR) of `abuf` from fp32 to (hi, lo) bf16 halves in place; item = (row, chunk pair g / g ^ 4), one thread each
     auto split_halo = [&](char* abuf) {
-        for (int id = t; id < HR * 4; id += NW * 64) {
+        auto slot = [&](int id, bool second) {
             const int hr = id >> 2, pg = ((id & 3) ^ hr) & 7;          // chunk c of row hr sits at position c ^ (hr & 7)
-            f32x4* pa = reinterpret_cast<f32x4*>(abuf + hr * 128 + (pg << 4));           // chunk g:     k = 4 g .. 4 g + 3
-            f32x4* pb = reinterpret_cast<f32x4*>(abuf + hr * 128 + ((pg ^ 4) << 4));     // chunk g + 4: k = 16 + 4 g ..
+            return reinterpret_cast<f32x4*>(abuf + hr * 128 + ((second ? pg ^ 4 : pg) << 4));   // chunk g: k = 4 g ..; chunk g + 4: k = 16 + 4 g ..
+        };
+        int id = t;
+        for (; id + NW * 64 < HR * 4; id += 2 * NW * 64) {             // two items per thread with their four reads in flight together
+            f32x4 *pa0 = slot(id, false), *pb0 = slot(id, true), *pa1 = slot(id + NW * 64, false), *pb1 = slot(id + NW * 64, true);
+            f32x4 va0 = *pa0, vb0 = *pb0, va1 = *pa1, vb1 = *pb1;
+            split_bf16_pair(va0, vb0);
+            *pa0 = va0; *pb0 = vb0;                                    // 8 hi halves (what the k-step-0 fragment address reads), 8 lo halves
+            split_bf16_pair(va1, vb1);
+            *pa1 = va1; *pb1 = vb1;
+        }
+        if (id < HR * 4) {
+            f32x4 *pa = slot(id, false), *pb = slot(id, true);
             f32x4 va = *pa, vb = *pb;
             split_bf16_pair(va, vb);
-            *pa = va;                                                  // 8 hi halves: what the k-step-0 fragment address reads
-            *pb = vb;                                                  // 8 lo halves: k-step 1
+            *pa = va; *pb = vb;
         }
     };
     if constexpr (SPLIT) {                 // slab 0: its pieces are older than the D * TG filter tiles of the prologue
@@ -3030,6 +3040,23 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
     return 0;
 }
 
+// The split-products variant is not MFMA-bound: per flop a 256-pixel tile reads 2/3 of the LDS fragment bytes and streams half the
+// filter bytes of a 128-pixel one (stamps: 893 cycles per tap on 128 pixels; the 16x16 layers on 256-pixel tiles run the same flops in
+// 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
+static int halo_tile_f32_split(const mdm_gemm_desc& d, int exact_choice) {
+    if (exact_choice == 64 || !(d.OW == 16 || d.OW == 32 || d.OW == 64)) return exact_choice;
+    int best = exact_choice;
+    double best_t = 1e30;
+    for (int bm : {256, 128}) {
+        if (bm % d.OW || d.OH % (bm / d.OW) || d.M % bm) continue;
+        if (halo_pieces(bm, d.OH, d.OW) > 48) continue;
+        const int64_t tiles = (int64_t)(d.M / bm) * (d.N / 64);
+        const double tm = (double)((tiles + 255) / 256) * (bm == 256 ? 1.46 : 1.0);
+        if (tm < best_t - 1e-9) { best_t = tm; best = bm; }
+    }
+    return best;
+}
+
 // conv_thin_k: 3x3 stride-1 "same" bf16 convolution with 8 (padded) input channels, layout 0 (forward, or the data gradient of an
 // 8-output-channel convolution through the transposed shadow), one source, plain epilogue (scale, bias, accumulate)
 static bool thin_conv(const mdm_gemm_desc& d) {
@@ -3062,7 +3089,9 @@ static int launch_f32_mfma_one(const mdm_gemm_desc& d, dim3 grid, hipStream_t s)
 template <int BM, int BN>
 static int launch_f32_mfma(const mdm_gemm_desc& d, dim3 grid, hipStream_t s) {
     switch (d.layout) {
-        case 0: return d.f32_split ? launch_f32_mfma_one<BM, BN, 0, true>(d, grid, s) : launch_f32_mfma_one<BM, BN, 0>(d, grid, s);
+        // (split products pay on the 128 x 128 tiles only: 77.6 -> 72.5 us per launch; on the 64 x 64 tiles the converting stores lengthen
+        //  a loop that is a load -> store -> barrier chain, 33 -> 51 us: measured, not taken)
+        case 0: return (d.f32_split && BM == 128) ? launch_f32_mfma_one<BM, BN, 0, BM == 128>(d, grid, s) : launch_f32_mfma_one<BM, BN, 0>(d, grid, s);
         case 1: return launch_f32_mfma_one<BM, BN, 1>(d, grid, s);
         default: return launch_f32_mfma_one<BM, BN, 2>(d, grid, s);
     }
@@ -3220,11 +3249,14 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             configured = bytes;
         }
         hipLaunchKernelGGL(tn_skinny_f32_kernel, dim3((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 64))), dim3(256), bytes, s, d);
-    } else if (const int hb32 = halo_tile_f32(d)) {
+    } else if (const int hb32_exact = halo_tile_f32(d)) {
         // exact-fp32 3x3 convolutions on the halo kernel (forward, folded upsample, transposed shadow): MFMA-bound
+        const int hb32 = hb32_exact;
         const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
         if (d.B_split != nullptr && !d.transposed) {
             // fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (conv_halo_body<..., SPLIT>)
+            const int hb32 = halo_tile_f32_split(d, hb32_exact);
+            const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
             if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, 2, 64, float, true>(d, s) : launch_halo<256, 6, 2, 64, float, true>(d, s);
             else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float, true>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float, true>(d, s)
                                                                                              : launch_halo<128, 6, 3, 64, float, true>(d, s);

@@ -345,9 +345,24 @@ __device__ __forceinline__ unsigned long long nstamp_now() {
 // [image][chunk][group][2] (plain stores, nothing to zero, fixed summation order), MODE 2 = apply.
 // NT = threads per workgroup: 512 on the larger slices (the kernels are VALU- and latency-bound at one wave per SIMD:
 // twice the waves per workgroup halve each thread's serial share of exp / rcp work)
-template <int NP, int MODE, int NT = 256>
-__global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0, const bf16_t* s1, int C1, int P, int G, int CBLK,
-                                                         float eps, const float* gamma, const float* beta, int silu, bf16_t* y,
+// (T = float, round 3: the fp32 forward -- the reverse sampler -- ran on the streaming kernel, two reads and a write per element;
+//  a lane's share of 8 channels x NP pixels is NP float8, 8 NP registers.)
+template <typename T> struct RegVec;
+template <> struct RegVec<bf16_t> {
+    typedef uint4 type;
+    static __device__ __forceinline__ uint4 zero() { return make_uint4(0, 0, 0, 0); }
+    static __device__ __forceinline__ uint4 ld(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ float8 unpack(const uint4& r) { return unpack8(r); }
+};
+template <> struct RegVec<float> {
+    typedef float8 type;
+    static __device__ __forceinline__ float8 zero() { return {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}; }
+    static __device__ __forceinline__ float8 ld(const float* p) { return load8(p); }
+    static __device__ __forceinline__ float8 unpack(const float8& r) { return r; }
+};
+template <int NP, int MODE, int NT = 256, typename T = bf16_t>
+__global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const T* s0, int C0, const T* s1, int C1, int P, int G, int CBLK,
+                                                         float eps, const float* gamma, const float* beta, int silu, T* y,
                                                          float* stats, float* ws) {
     constexpr int CS_PITCH = NT + 4;
     const int C = C0 + C1, cpg = div_small(C, rcp_small(G));
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
     // loading its 8 pivots itself and the statistics thread loading its pivot AGAIN after the reduction put a second
     // memory round trip on the critical path of a ~3 us kernel
     if (t < ng && g0 + t < G) gpiv[t] = gn_pivot(s0, s1, C0, C1, base, g0 + t, cpg);
-    uint4 cx[NP];
+    typename RegVec<T>::type cx[NP];
     float part[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) part[k] = 0.f;
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             int p = pbeg + lane + i * PL;
-            cx[i] = p < pend ? *reinterpret_cast<const uint4*>(src_ptr(s0, s1, C0, C1, base + p, c)) : make_uint4(0, 0, 0, 0);
+            cx[i] = p < pend ? RegVec<T>::ld(src_ptr(s0, s1, C0, C1, base + p, c)) : RegVec<T>::zero();
         }
     }
     __syncthreads();
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (pbeg + lane + i * PL < pend) {
-                float8 x = unpack8(cx[i]);
+                float8 x = RegVec<T>::unpack(cx[i]);
                 float xv[8] = F8_TO_ARR(x);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float dlt = xv[e] - K[e]; part[e] += dlt; part[8 + e] = fmaf(dlt, dlt, part[8 + e]); }
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const bf16_t* s0, int C0
         for (int i = 0; i < NP; ++i) {
             int p = pbeg + lane + i * PL;
             if (p < pend) {
-                float8 x = unpack8(cx[i]);
+                float8 x = RegVec<T>::unpack(cx[i]);
                 float xv[8] = F8_TO_ARR(x);
                 float o[8];
 #pragma unroll
@@ -866,6 +881,14 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     if (dtype == MDM_BF16 && np <= 16) {
 #define GN_FWD_REG(NPV, NT) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV, 0, NT>), grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)src0, C0, \
                                                (const bf16_t*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (bf16_t*)y, stats, ws)
+        if (np <= 1) GN_FWD_REG(1, 256); else if (np <= 2) GN_FWD_REG(2, 256); else if (np <= 4) GN_FWD_REG(2, 512);
+        else if (np <= 8) GN_FWD_REG(4, 512); else GN_FWD_REG(8, 512);
+#undef GN_FWD_REG
+        return launch_status("groupnorm_fwd");
+    }
+    if (dtype == MDM_F32 && np <= 16) {            // the same kernels on fp32 storage: one read of the slice instead of two
+#define GN_FWD_REG(NPV, NT) hipLaunchKernelGGL((gn_fwd_reg_kernel<NPV, 0, NT, float>), grid, dim3(NT), 0, (hipStream_t)stream, (const float*)src0, C0, \
+                                               (const float*)src1, C1, P, G, cblk, eps, gamma, beta, silu, (float*)y, stats, ws)
         if (np <= 1) GN_FWD_REG(1, 256); else if (np <= 2) GN_FWD_REG(2, 256); else if (np <= 4) GN_FWD_REG(2, 512);
         else if (np <= 8) GN_FWD_REG(4, 512); else GN_FWD_REG(8, 512);
 #undef GN_FWD_REG

@@ -448,11 +448,13 @@ def test_train_step_gradient_tensors_vs_reference(golden, dt):
         assert abs(tr.optimizer.grad_norm() - float(g["tg_norm"])) < 2e-4 * float(g["tg_norm"])       # what the clip used
 
 
-def test_sampler_trajectories_10_and_50_steps_vs_reference(golden):
+@pytest.mark.parametrize("products", ["exact", "split"])
+def test_sampler_trajectories_10_and_50_steps_vs_reference(golden, products):
+    """`split`: fp32 storage with the convolutions' products as bf16 hi / lo pairs (UNet(f32_products="split")) -- the same 1e-3 bar."""
     import mdm
     from oracle.unet_ref import random_params
     g = golden("sampler_long")
-    model = mdm.UNet(TINY, N=2, H=16, W=16, dtype=0, params=random_params(TINY)).eval()
+    model = mdm.UNet(TINY, N=2, H=16, W=16, dtype=0, params=random_params(TINY), f32_products=products).eval()
     for i in range(int(g["long_n"])):
         dep, mode, sel, ch, kind, st, Tn = [str(v) for v in g[f"long{i}_cfg"]]
         Tn = int(Tn)
