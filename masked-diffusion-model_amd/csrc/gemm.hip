@@ -2777,6 +2777,107 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 }
 
 // ----------------------------------------------------------------------------
+// lin_split: 1x1 stride-1 convolution over one or two fp32 NHWC sources (a ResidualBlock's skip projection over the concatenated
+// decoder input, the attention block's project_in / project_out: unet6.py:296-333, 350-362) with SPLIT products -- the companion of
+// conv_halo_body<..., SPLIT> for the layers that have no halo to reuse.  On the register-staged fp32 kernel these launches were a
+// load -> store -> barrier chain per 32-deep slab (66 TFLOP/s at sample_num = 100, three times their HBM time).
+//   tile 128 pixels x BN channels, 8 waves as 4 x 2; per 32-channel slab both operand tiles arrive by LDS-DMA in a four-stage ring
+//   (slab s in stage s & 3): while slab s multiplies, slab s+1 (landed) is split in place -- 128 rows x 4 chunk pairs = one item per
+//   thread --, slab s+2 is in flight and slab s+3 is issued into the stage slab s-1 has left.  ONE barrier per slab.  Filters come
+//   already split from B_split.  Same swizzle, chunk pairing (g, g ^ 4) and product order as the halo kernel; epilogue_tile.
+// Requires: KH = KW = 1, stride 1, no pads / upsample, C0 % 32 == C1 % 32 == 0, M % 128 == 0, N % BN == 0.
+// ----------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
+    constexpr int BM = 128, NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
+    constexpr int NS = 4, A_ST = BM * 128, B_ST = BN * 128, GA = BM / 64, GB = BN / 64, G = GA + GB;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* const aring = lds;
+    char* const bring = lds + NS * A_ST;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int tiles_n = d.N / BN;
+    const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
+    const int NCS = d.Ck >> 5, C0 = d.C0;
+    const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+    const int lch16 = ((lane & 7) ^ (lane >> 3)) << 4;
+    const char* a0[GA];
+    const char* a1[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        const int64_t m = m0 + 8 * (wave * GA + j) + (lane >> 3);
+        a0[j] = reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.src0) + m * d.ld0) + lch16;
+        a1[j] = d.C1 ? reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.src1) + m * d.ld1) + lch16 : zlane;
+    }
+    const char* b0[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int64_t n = n0 + 8 * (wave * GB + j) + (lane >> 3);
+        b0[j] = reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.B_split) + n * d.ldb) + lch16;
+    }
+    auto issue = [&](int cs) {                                      // every wave issues G operations per slab, live or not
+        const int st = cs & (NS - 1), c = cs << 5;
+        const bool live = cs < NCS, s1 = c >= C0;
+#pragma unroll
+        for (int j = 0; j < GA; ++j)
+            lds_dma16(live ? (s1 ? a1[j] + (int64_t)(c - C0) * 4 : a0[j] + (int64_t)c * 4) : zlane, aring + st * A_ST + (wave * GA + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < GB; ++j) lds_dma16(live ? b0[j] + (int64_t)c * 4 : zlane, bring + st * B_ST + (wave * GB + j) * 1024);
+    };
+    auto split_a = [&](int cs) {                                    // rows x chunk pairs of stage cs & 3: one item per thread
+        char* abuf = aring + (cs & (NS - 1)) * A_ST;
+        const int hr = t >> 2, pg = ((t & 3) ^ hr) & 7;
+        f32x4* pa = reinterpret_cast<f32x4*>(abuf + hr * 128 + (pg << 4));
+        f32x4* pb = reinterpret_cast<f32x4*>(abuf + hr * 128 + ((pg ^ 4) << 4));
+        f32x4 va = *pa, vb = *pb;
+        split_bf16_pair(va, vb);
+        *pa = va; *pb = vb;
+    };
+    issue(0); issue(1); issue(2);
+    int a_off[MI], b_off[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ml = wr * WM + i * 16 + (lane & 15);
+        a_off[i] = ml * 128 + (((lane >> 4) ^ (ml & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int nl = wc * WN + j * 16 + (lane & 15);
+        b_off[j] = nl * 128 + (((lane >> 4) ^ (nl & 7)) << 4);
+    }
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    wait_vmcnt<2 * G>();                                            // slab 0 has landed
+    __builtin_amdgcn_s_barrier();
+    split_a(0);
+    for (int s = 0; s < NCS; ++s) {
+        wait_vmcnt<G>();                                            // slabs <= s+1 have landed (this wave's pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the split of slab s is written
+        __builtin_amdgcn_s_barrier();                               // ... for every wave; slab s-1 is no longer read
+        issue(s + 3);
+        if (s + 1 < NCS) split_a(s + 1);
+        const char* As = aring + (s & (NS - 1)) * A_ST;
+        const char* Bs = bring + (s & (NS - 1)) * B_ST;
+        f32x4 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { bh[j] = *reinterpret_cast<const f32x4*>(Bs + b_off[j]); bl[j] = *reinterpret_cast<const f32x4*>(Bs + (b_off[j] ^ 64)); }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { ah[i] = *reinterpret_cast<const f32x4*>(As + a_off[i]); al[i] = *reinterpret_cast<const f32x4*>(As + (a_off[i] ^ 64)); }
+        halo_mma_split<MI, NI>(acc, bh, al);
+        halo_mma_split<MI, NI>(acc, bl, ah);
+        halo_mma_split<MI, NI>(acc, bh, ah);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    epilogue_tile<BM, BN, NW, MI, NI, float>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+}
+
+// ----------------------------------------------------------------------------
 // The two ENDS of the U-Net (unet6.py:403-404, 505): 3 -> 128 channels in, 128 -> 3 out, with the 3 padded to 8 -- one 16-byte chunk
 // per pixel.  Through the general kernels these ran ~20 us each for 0.6 GFLOP (k-slabs that are not 64-aligned fall back to the
 // register-staged kernel: two 64-deep slabs of per-element gather arithmetic and an 8-byte scattered epilogue).  They are memory-bound
@@ -3043,6 +3144,30 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
 // The split-products variant is not MFMA-bound: per flop a 256-pixel tile reads 2/3 of the LDS fragment bytes and streams half the
 // filter bytes of a 128-pixel one (stamps: 893 cycles per tap on 128 pixels; the 16x16 layers on 256-pixel tiles run the same flops in
 // 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
+// lin_split_kernel: 0 = not eligible, else the channel tile (128, or 64 when 128 would leave the chip short of workgroups)
+static int lin_split_tile(const mdm_gemm_desc& d) {
+    if (!(d.dtype == MDM_F32 && d.B_split != nullptr && d.layout == 0 && d.conv && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.ups == 0 &&
+          !d.transposed && d.pad_t == 0 && d.pad_l == 0 && d.IH == d.OH && d.IW == d.OW && d.C0 % 32 == 0 && d.C1 % 32 == 0 && d.C0 > 0 &&
+          d.Ck == d.C0 + d.C1 && d.K == d.Ck && d.M % 128 == 0 && d.N % 64 == 0 && d.N0 % 8 == 0 && d.splitk <= 1 && d.batch <= 1 &&
+          d.ldb % 4 == 0 && d.ld0 % 4 == 0 && d.ld1 % 4 == 0))
+        return 0;
+    if (d.N % 128 == 0 && (int64_t)(d.M / 128) * (d.N / 128) >= kBigMinTiles) return 128;
+    return 64;
+}
+template <int BN>
+static int launch_lin_split(const mdm_gemm_desc& d, hipStream_t s) {
+    constexpr int bytes = 4 * (128 * 128 + BN * 128);
+    static bool configured = false;
+    if (!configured) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_split_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((lin_split_kernel<BN>), dim3((unsigned)((int64_t)(d.M / 128) * (d.N / BN))), dim3(512), bytes, s, d);
+    return 0;
+}
+#ifndef MDM_SPLIT_NSB256
+#define MDM_SPLIT_NSB256 2          // filter stages of the 256-pixel split tiles
+#endif
 static int halo_tile_f32_split(const mdm_gemm_desc& d, int exact_choice) {
     if (exact_choice == 64 || !(d.OW == 16 || d.OW == 32 || d.OW == 64)) return exact_choice;
     int best = exact_choice;
@@ -3249,6 +3374,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             configured = bytes;
         }
         hipLaunchKernelGGL(tn_skinny_f32_kernel, dim3((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 64))), dim3(256), bytes, s, d);
+    } else if (const int lsb = lin_split_tile(d)) {
+        rc = lsb == 128 ? launch_lin_split<128>(d, s) : launch_lin_split<64>(d, s);
     } else if (const int hb32_exact = halo_tile_f32(d)) {
         // exact-fp32 3x3 convolutions on the halo kernel (forward, folded upsample, transposed shadow): MFMA-bound
         const int hb32 = hb32_exact;
@@ -3257,7 +3384,7 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             // fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (conv_halo_body<..., SPLIT>)
             const int hb32 = halo_tile_f32_split(d, hb32_exact);
             const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
-            if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, 2, 64, float, true>(d, s) : launch_halo<256, 6, 2, 64, float, true>(d, s);
+            if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, MDM_SPLIT_NSB256, 64, float, true>(d, s) : launch_halo<256, 6, MDM_SPLIT_NSB256, 64, float, true>(d, s);
             else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float, true>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float, true>(d, s)
                                                                                              : launch_halo<128, 6, 3, 64, float, true>(d, s);
             else if ((int64_t)(d.M / 64) * (d.N / 64) < kBigMinTiles && d.N % 32 == 0)

@@ -309,6 +309,37 @@ def test_f32_split_register_staged(case):
     assert torch.equal(outs["exact"], outs["split"]) != taken, "f32_split: wrong kernel for this shape"
 
 
+@pytest.mark.parametrize("case", [(100, 16, 256, 256, 256), (100, 32, 256, 128, 128), (100, 8, 256, 0, 768), (100, 8, 256, 0, 256),
+                                  (8, 8, 128, 128, 256), (2, 8, 64, 0, 64), (6, 8, 32, 0, 128)])
+def test_lin_split_products(case):
+    """lin_split_kernel: 1x1 convolutions (skip projections over a concat, attention projections) with split products -- both channel
+    tiles, one and two sources, bias + residual: within 2e-5 of fp64, and not the exact kernel's bits."""
+    from mdm import ops
+    N, H, C0, C1, Cout = case
+    C = C0 + C1
+    g = torch.Generator().manual_seed(N + H + C + Cout)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(Cout, C, 1, 1, generator=g) / C ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, Cout, H, H, generator=g)
+    y = (F.conv2d(x.double(), w.double(), b.double()) + res.double()).float()
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, KH=1, KW=1, pad_t=0, pad_l=0, pad_b=0, pad_r=0)
+    xh = _nhwc(x)
+    s0 = xh[..., :C0].contiguous().to(_dev())
+    s1 = xh[..., C0:].contiguous().to(_dev()) if C1 else None
+    P, Ps = _split_shadow(_w_tap(w))
+    outs = {}
+    for tag, wsplit in (("exact", None), ("split", Ps)):
+        out = torch.full((N, H, H, Cout), float("nan"), device=_dev())
+        ops.conv_fwd(0, geom, s0, s1, P, b.to(_dev()), out, resid=_nhwc(res).to(_dev()), w_split=wsplit)
+        torch.cuda.synchronize()
+        outs[tag] = out
+    e_exact, e_split = _relerr(outs["exact"], _nhwc(y)), _relerr(outs["split"], _nhwc(y))
+    assert e_exact < 1e-6, e_exact
+    assert e_split < 2e-5, e_split
+    assert not torch.equal(outs["exact"], outs["split"]), "B_split was ignored: lin_split_kernel did not run"
+
+
 def test_conv_tap_split_with_epilogue():
     """Small-M 3x3 conv: reduction split over the filter taps (slabs + epilogue kernel), full epilogue."""
     from mdm import ops
