@@ -3165,10 +3165,16 @@ static int launch_lin_split(const mdm_gemm_desc& d, hipStream_t s) {
     hipLaunchKernelGGL((lin_split_kernel<BN>), dim3((unsigned)((int64_t)(d.M / 128) * (d.N / BN))), dim3(512), bytes, s, d);
     return 0;
 }
+#ifndef MDM_SPLIT_MIN128
+#define MDM_SPLIT_MIN128 160
+#endif
 #ifndef MDM_SPLIT_NSB256
 #define MDM_SPLIT_NSB256 2          // filter stages of the 256-pixel split tiles
 #endif
 static int halo_tile_f32_split(const mdm_gemm_desc& d, int exact_choice) {
+    // 8x8 maps: two whole images per tile when that still gives every CU a tile (sample_num = 100, 256 channels: 400 tiles of 64
+    // pixels = 1.56 rounds at 16 % of the matrix pipe inside the loop; 200 tiles of 128 pixels = one round)
+    if (exact_choice == 64 && d.OW == 8 && d.OH == 8 && d.M % 128 == 0 && (int64_t)(d.M / 128) * (d.N / 64) >= MDM_SPLIT_MIN128) return 128;
     if (exact_choice == 64 || !(d.OW == 16 || d.OW == 32 || d.OW == 64)) return exact_choice;
     int best = exact_choice;
     double best_t = 1e30;

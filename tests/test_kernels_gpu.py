@@ -240,7 +240,8 @@ def test_split_shadow_layout():
 
 @pytest.mark.parametrize("case", [(32, 32, 128, 0, 128, 0), (100, 32, 128, 0, 128, 0), (25, 16, 64, 64, 256, 0), (8, 64, 32, 0, 64, 0),
                                   (8, 8, 128, 0, 128, 0), (16, 4, 64, 64, 256, 0), (4, 4, 512, 0, 512, 0),
-                                  (8, 8, 96, 0, 128, 1), (12, 16, 256, 0, 128, 1)])
+                                  (8, 8, 96, 0, 128, 1), (12, 16, 256, 0, 128, 1),
+                                  (100, 8, 256, 0, 256, 0)])               # 8x8 maps with enough tiles: two images per 128-pixel tile
 def test_conv_halo_split_products(case):
     """fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (mdm_gemm_desc.B_split, conv_halo_body<..., SPLIT>): every
     halo tile shape, two sources, folded upsample, the sampler's 100-image batch.  Against an fp64 convolution the split path must stay
