@@ -3165,6 +3165,9 @@ static int launch_lin_split(const mdm_gemm_desc& d, hipStream_t s) {
     hipLaunchKernelGGL((lin_split_kernel<BN>), dim3((unsigned)((int64_t)(d.M / 128) * (d.N / BN))), dim3(512), bytes, s, d);
     return 0;
 }
+#ifndef MDM_NSB256
+#define MDM_NSB256 2                // filter stages of the 256-pixel bf16 halo tiles
+#endif
 #ifndef MDM_SPLIT_MIN128
 #define MDM_SPLIT_MIN128 160
 #endif
@@ -3420,8 +3423,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
     } else if (const ConvVar cv = conv_variant(d, r, grid.z)) {
         const dim3 g2((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 128)), 1, grid.z);
         switch (cv) {
-            case CV_H256_4: rc = launch_halo<256, 4, 2>(d, s); break;
-            case CV_H256_6: rc = launch_halo<256, 6, 2>(d, s); break;
+            case CV_H256_4: rc = launch_halo<256, 4, MDM_NSB256>(d, s); break;
+            case CV_H256_6: rc = launch_halo<256, 6, MDM_NSB256>(d, s); break;
             case CV_H128_3: rc = launch_halo<128, 3, 3>(d, s); break;
             case CV_H128_4: rc = launch_halo<128, 4, 3>(d, s); break;
             case CV_H128_6: rc = launch_halo<128, 6, 3>(d, s); break;
@@ -3522,7 +3525,7 @@ extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b
         else if (va == CV_H64_3_32 && vb == CV_L64) rc = launch_pair<64, 3, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H128_3 && vb == CV_L64x128) rc = launch_pair<128, 3, 64, 3, 64, 128, 3, 2, 4>(a, b, nb64x128, s);
         else if (va == CV_H128_3 && vb == CV_L64) rc = launch_pair<128, 3, 64, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
-        else if (va == CV_H256_6 && vb == CV_L128) rc = launch_pair<256, 6, 64, 2, 128, 128, 3, 4, 2>(a, b, nb64, s);
+        else if (va == CV_H256_6 && vb == CV_L128) rc = launch_pair<256, 6, 64, MDM_NSB256, 128, 128, 3, 4, 2>(a, b, nb64, s);
     }
     if (rc == -2) {
         rc = gemm_launch(a_host, s);

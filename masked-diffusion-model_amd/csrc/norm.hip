@@ -857,6 +857,9 @@ static int gn_check(int C0, int C1, int G, int N, int P) {
 }
 
 // channels per workgroup: whole groups, whole 16-byte vectors, at least 32 channels
+#ifndef MDM_GN_F32_CBLK32
+#define MDM_GN_F32_CBLK32 1
+#endif
 static int gn_cblk(int C, int G, int N, int P) {
     int cpg = C / G, l = cpg;
     while (l % 8) l += cpg;            // lcm(cpg, 8)
@@ -874,7 +877,14 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
                                  float eps, const float* gamma, const float* beta, int silu, void* y, float* stats,
                                  float* ws, void* stream) {
     if (int rc = gn_check(C0, C1, G, N, P)) return rc;
-    const int C = C0 + C1, cblk = gn_cblk(C, G, N, P);
+    const int C = C0 + C1;
+    int cblk = gn_cblk(C, G, N, P);
+    // fp32 forward on large maps: 32 channels per workgroup = whole 128-byte lines per pixel (16 fp32 channels are 64-byte pieces:
+    // 3.0 TB/s on the sampler's 32x32x128 maps), as long as the slice still fits the register-cached kernels
+    if (dtype == MDM_F32 && P > 256 && MDM_GN_F32_CBLK32) {
+        const int wide = gn_cblk(C, G, N, 256);
+        if (cdiv(P, 256 / (wide / 8)) <= 16) cblk = wide;
+    }
     MDM_REQUIRE(cblk <= 64 && cblk / (C / G) <= 64, "groupnorm: unsupported channel/group combination C=%d G=%d", C, G);
     dim3 grid(N, cdiv(C, cblk));
     const int np = cdiv(P, 256 / (cblk / 8));          // 16-byte vectors per lane of a 256-thread workgroup
