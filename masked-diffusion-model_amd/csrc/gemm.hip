@@ -2574,7 +2574,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     const int rows_sh = __builtin_ctz(R) + ow_sh;                               // R * OW is a power of two
     char* const bring = lds + 2 * ABUF;
     char* const dummy = bring + NSB * STAGE_B;
-    const int tiles_n = d.N / BN;
+    const int tiles_n = (d.N + BN - 1) / BN;                     // (N < BN: the last convolution's 8 output channels as one partly filled tile)
     // XCD-aware tile order (xcd_remap): the output-channel tiles of one pixel tile read the same halo and neighbouring
     // pixel tiles the same filter slabs -- handing each XCD a CONTIGUOUS eighth of the tile list lets them meet in ONE L2
     // instead of eight.  No effect on time at cfg2 (the loop is bound by the CU's intake, not by L2 misses); it is there
@@ -2613,9 +2613,10 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     const bool b_wave = wave * 8 < BN;
     const int bn = n0 + (b_wave ? wave * 8 : 0) + (lane >> 3);
     const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const T*>(SPLIT ? d.B_split : d.B) + (int64_t)bn * d.ldb) + lch16;
+    const bool b_live = b_wave && bn < d.N;                          // filter rows beyond N (a partly filled channel tile) are zeros
     auto issue_b = [&](int tap, int cs, int lds_off) {               // lds_off: byte offset of the tile inside the ring
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * KC) * (int64_t)sizeof(T);
-        lds_dma16((cs < NCS && b_wave) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
+        lds_dma16((cs < NCS && b_live) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
     };
 
     // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..D-1 (in flight while the offset tables below are built)
@@ -2785,7 +2786,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 //   (slab s in stage s & 3): while slab s multiplies, slab s+1 (landed) is split in place -- 128 rows x 4 chunk pairs = one item per
 //   thread --, slab s+2 is in flight and slab s+3 is issued into the stage slab s-1 has left.  ONE barrier per slab.  Filters come
 //   already split from B_split.  Same swizzle, chunk pairing (g, g ^ 4) and product order as the halo kernel; epilogue_tile.
-// Requires: KH = KW = 1, stride 1, no pads / upsample, C0 % 32 == C1 % 32 == 0, M % 128 == 0, N % BN == 0.
+// Also the stride-2 3x3 convolutions (SamePad2d + stride 2, unet6.py:257-272): a filter tap is a constant source-pixel offset and a
+// per-row validity bit, the slab loop runs tap-major over taps x channel slabs (on the register-staged kernel those three launches
+// took 355 us of a 6.3 ms reverse step).  Rows beyond M read the zero page and are skipped by the epilogue.
+// Requires: KH = KW in {1, 3}, stride 1 (1x1) or 2, no upsample, C0 % 32 == C1 % 32 == 0, N % BN == 0.
 // ----------------------------------------------------------------------------
 template <int BN>
 __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
@@ -2800,31 +2804,51 @@ __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
     const int tiles_n = d.N / BN;
     const int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
-    const int NCS = d.Ck >> 5, C0 = d.C0;
+    const int NCS = d.Ck >> 5, C0 = d.C0, KW = d.KW, NSL = d.KH * d.KW * NCS;     // slabs: filter tap major, 32-channel slab minor
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int lch16 = ((lane & 7) ^ (lane >> 3)) << 4;
+    // row m = output pixel (img, oy, ox); filter tap (ty, tx) reads source pixel (oy * stride - pad_t + ty, ox * stride - pad_l + tx):
+    // one pointer per row for tap (0, 0), a constant pixel offset per tap, and a 9-bit mask of the taps that fall inside the image
     const char* a0[GA];
     const char* a1[GA];
+    unsigned tapmask[GA];
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-        const int64_t m = m0 + 8 * (wave * GA + j) + (lane >> 3);
-        a0[j] = reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.src0) + m * d.ld0) + lch16;
-        a1[j] = d.C1 ? reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.src1) + m * d.ld1) + lch16 : zlane;
+        const int m = m0 + 8 * (wave * GA + j) + (lane >> 3);
+        const RowPix rp = decode_row(d, m < d.M ? m : 0);
+        const int iy0 = rp.oy * d.stride - d.pad_t, ix0 = rp.ox * d.stride - d.pad_l;
+        const int64_t pix0 = ((int64_t)rp.img * d.IH + iy0) * d.IW + ix0;
+        unsigned mk = 0;
+        for (int tp = 0; tp < d.KH * KW; ++tp) {
+            const int ty = tp / KW, tx = tp - ty * KW;
+            if (m < d.M && (unsigned)(iy0 + ty) < (unsigned)d.IH && (unsigned)(ix0 + tx) < (unsigned)d.IW) mk |= 1u << tp;
+        }
+        tapmask[j] = mk;
+        a0[j] = reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.src0) + pix0 * d.ld0) + lch16;
+        a1[j] = d.C1 ? reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.src1) + pix0 * d.ld1) + lch16 : zlane;
     }
+    const int ld0b = d.ld0 * 4, ld1b = d.ld1 * 4, IWs = d.IW;
+    const int64_t wtapb = d.wtap * 4;
     const char* b0[GB];
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
         const int64_t n = n0 + 8 * (wave * GB + j) + (lane >> 3);
         b0[j] = reinterpret_cast<const char*>(reinterpret_cast<const float*>(d.B_split) + n * d.ldb) + lch16;
     }
-    auto issue = [&](int cs) {                                      // every wave issues G operations per slab, live or not
-        const int st = cs & (NS - 1), c = cs << 5;
-        const bool live = cs < NCS, s1 = c >= C0;
+    int is_tap = 0, is_cs = 0, is_ty = 0, is_tx = 0;                // (tap, slab) of the next slab to issue: issue() is called in slab order
+    auto issue = [&](int sl) {                                      // every wave issues G operations per slab, live or not
+        const int st = sl & (NS - 1), c = is_cs << 5;
+        const bool live = sl < NSL, s1 = c >= C0;
+        const int poff = is_ty * IWs + is_tx;                       // source pixels between tap (0, 0) and this tap
 #pragma unroll
-        for (int j = 0; j < GA; ++j)
-            lds_dma16(live ? (s1 ? a1[j] + (int64_t)(c - C0) * 4 : a0[j] + (int64_t)c * 4) : zlane, aring + st * A_ST + (wave * GA + j) * 1024);
+        for (int j = 0; j < GA; ++j) {
+            const bool ok = live && ((tapmask[j] >> is_tap) & 1u);
+            const char* src = s1 ? a1[j] + (int64_t)poff * ld1b + (int64_t)(c - C0) * 4 : a0[j] + (int64_t)poff * ld0b + (int64_t)c * 4;
+            lds_dma16(ok ? src : zlane, aring + st * A_ST + (wave * GA + j) * 1024);
+        }
 #pragma unroll
-        for (int j = 0; j < GB; ++j) lds_dma16(live ? b0[j] + (int64_t)c * 4 : zlane, bring + st * B_ST + (wave * GB + j) * 1024);
+        for (int j = 0; j < GB; ++j) lds_dma16(live ? b0[j] + is_tap * wtapb + (int64_t)c * 4 : zlane, bring + st * B_ST + (wave * GB + j) * 1024);
+        if (++is_cs == NCS) { is_cs = 0; ++is_tap; if (++is_tx == KW) { is_tx = 0; ++is_ty; } }
     };
     auto split_a = [&](int cs) {                                    // rows x chunk pairs of stage cs & 3: one item per thread
         char* abuf = aring + (cs & (NS - 1)) * A_ST;
@@ -2855,12 +2879,12 @@ __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
     wait_vmcnt<2 * G>();                                            // slab 0 has landed
     __builtin_amdgcn_s_barrier();
     split_a(0);
-    for (int s = 0; s < NCS; ++s) {
+    for (int s = 0; s < NSL; ++s) {
         wait_vmcnt<G>();                                            // slabs <= s+1 have landed (this wave's pieces)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the split of slab s is written
         __builtin_amdgcn_s_barrier();                               // ... for every wave; slab s-1 is no longer read
         issue(s + 3);
-        if (s + 1 < NCS) split_a(s + 1);
+        if (s + 1 < NSL) split_a(s + 1);
         const char* As = aring + (s & (NS - 1)) * A_ST;
         const char* Bs = bring + (s & (NS - 1)) * B_ST;
         f32x4 ah[MI], al[MI], bh[NI], bl[NI];
@@ -3087,7 +3111,7 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filt
                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
-    dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / BN)));
+    dim3 grid((unsigned)((int64_t)(d.M / BM) * cdiv(d.N, BN)));
     hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T, SPLIT>), grid, dim3(512), bytes, s, d);
     return 0;
 }
@@ -3144,14 +3168,27 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
 // The split-products variant is not MFMA-bound: per flop a 256-pixel tile reads 2/3 of the LDS fragment bytes and streams half the
 // filter bytes of a 128-pixel one (stamps: 893 cycles per tap on 128 pixels; the 16x16 layers on 256-pixel tiles run the same flops in
 // 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
+// The LAST convolution of the net (128 -> 3, padded to 8 output channels; unet6.py:505) with split products: on the register-staged
+// kernel its 64-wide tiles were 8 real channels each and it took 172 us of the reverse step -- more than a 128 -> 128 layer.  On the
+// 256-pixel halo tiles with a 32-channel tile (one 16-wide MFMA column per wave, rows beyond N zero): 0 = not eligible, else 256.
+static int halo_small_n_split(const mdm_gemm_desc& d) {
+    if (!(d.dtype == MDM_F32 && d.B_split != nullptr && d.layout == 0 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.ups == 0 &&
+          !d.transposed && d.pad_t == 1 && d.pad_l == 1 && d.IH == d.OH && d.IW == d.OW && d.C0 % 32 == 0 && d.C1 % 32 == 0 &&
+          d.Ck == d.C0 + d.C1 && d.N % 8 == 0 && d.N <= 32 && d.N0 % 8 == 0 && d.splitk <= 1 && (d.OH & (d.OH - 1)) == 0 &&
+          (d.OW == 16 || d.OW == 32) && d.OH % (256 / d.OW) == 0 && d.M % 256 == 0 && halo_pieces(256, d.OH, d.OW) <= 48 && d.M / 256 >= 128))
+        return 0;
+    return 256;
+}
 // lin_split_kernel: 0 = not eligible, else the channel tile (128, or 64 when 128 would leave the chip short of workgroups)
 static int lin_split_tile(const mdm_gemm_desc& d) {
-    if (!(d.dtype == MDM_F32 && d.B_split != nullptr && d.layout == 0 && d.conv && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.ups == 0 &&
-          !d.transposed && d.pad_t == 0 && d.pad_l == 0 && d.IH == d.OH && d.IW == d.OW && d.C0 % 32 == 0 && d.C1 % 32 == 0 && d.C0 > 0 &&
-          d.Ck == d.C0 + d.C1 && d.K == d.Ck && d.M % 128 == 0 && d.N % 64 == 0 && d.N0 % 8 == 0 && d.splitk <= 1 && d.batch <= 1 &&
-          d.ldb % 4 == 0 && d.ld0 % 4 == 0 && d.ld1 % 4 == 0))
+    const bool k1 = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_t == 0 && d.pad_l == 0 && d.IH == d.OH && d.IW == d.OW;
+    const bool s2 = d.KH == 3 && d.KW == 3 && d.stride == 2 && d.pad_t >= 0 && d.pad_l >= 0 && d.pad_t <= 1 && d.pad_l <= 1;
+    if (!(d.dtype == MDM_F32 && d.B_split != nullptr && d.layout == 0 && d.conv && (k1 || s2) && d.ups == 0 && !d.transposed &&
+          d.C0 % 32 == 0 && d.C1 % 32 == 0 && d.C0 > 0 && d.Ck == d.C0 + d.C1 && d.K == d.KH * d.KW * d.Ck && d.N % 64 == 0 && d.N0 % 8 == 0 &&
+          d.splitk <= 1 && d.batch <= 1 && d.ldb % 4 == 0 && d.ld0 % 4 == 0 && d.ld1 % 4 == 0 && d.M >= 64 &&
+          (int64_t)d.M * d.ld0 < (1ll << 40)))
         return 0;
-    if (d.N % 128 == 0 && (int64_t)(d.M / 128) * (d.N / 128) >= kBigMinTiles) return 128;
+    if (d.N % 128 == 0 && (int64_t)cdiv(d.M, 128) * (d.N / 128) >= kBigMinTiles) return 128;
     return 64;
 }
 template <int BN>
@@ -3162,7 +3199,7 @@ static int launch_lin_split(const mdm_gemm_desc& d, hipStream_t s) {
         MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_split_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((lin_split_kernel<BN>), dim3((unsigned)((int64_t)(d.M / 128) * (d.N / BN))), dim3(512), bytes, s, d);
+    hipLaunchKernelGGL((lin_split_kernel<BN>), dim3((unsigned)((int64_t)cdiv(d.M, 128) * (d.N / BN))), dim3(512), bytes, s, d);
     return 0;
 }
 #ifndef MDM_NSB256
@@ -3385,6 +3422,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
         hipLaunchKernelGGL(tn_skinny_f32_kernel, dim3((unsigned)((int64_t)cdiv(d.M, 64) * cdiv(d.N, 64))), dim3(256), bytes, s, d);
     } else if (const int lsb = lin_split_tile(d)) {
         rc = lsb == 128 ? launch_lin_split<128>(d, s) : launch_lin_split<64>(d, s);
+    } else if (halo_small_n_split(d)) {
+        rc = (halo_pieces(256, d.OH, d.OW) + 7) / 8 <= 4 ? launch_halo<256, 4, 2, 32, float, true>(d, s) : launch_halo<256, 6, 2, 32, float, true>(d, s);
     } else if (const int hb32_exact = halo_tile_f32(d)) {
         // exact-fp32 3x3 convolutions on the halo kernel (forward, folded upsample, transposed shadow): MFMA-bound
         const int hb32 = hb32_exact;

@@ -16,9 +16,11 @@ from mdm import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--products", default="exact", choices=["exact", "split"], help="fp32 only: UNet(f32_products=...)")
+ap.add_argument("--fwd-only", action="store_true", help="the forward launch list only (the reverse sampler's U-Net call)")
 o = ap.parse_args()
 dt = mdm.BF16 if o.dtype == "bf16" else mdm.F32
-model = mdm.UNet(mdm.unet6_config(32), N=o.batch, H=32, W=32, dtype=dt, seed=0, use_graph=False)
+model = mdm.UNet(mdm.unet6_config(32), N=o.batch, H=32, W=32, dtype=dt, seed=0, use_graph=False, f32_products=o.products)
 st = torch.cuda.current_stream().cuda_stream
 
 
@@ -32,13 +34,13 @@ def describe(name, args):
     if d.conv:
         s += f" conv {d.KH}x{d.KW} s{d.stride} {d.IH}x{d.IW}->{d.OH}x{d.OW} C{d.C0}+{d.C1} T{d.transposed} ups{d.ups}"
     s += f" sk{d.splitk}"
-    for f in ("gnb_x", "gnf_out", "resid", "rowvec", "dbias", "gnb_add"):
+    for f in ("gnb_x", "gnf_out", "resid", "rowvec", "dbias", "gnb_add", "B_split", "f32_split"):
         if getattr(d, f):
             s += " " + f
     return s
 
 
-for tag, rec in (("fwd", model.forward_plan), ("bwd", model.backward_plan)):
+for tag, rec in (("fwd", model.forward_plan),) if o.fwd_only else (("fwd", model.forward_plan), ("bwd", model.backward_plan)):
     runs = []
     for _ in range(5):
         model.zero_grad()

@@ -241,7 +241,8 @@ def test_split_shadow_layout():
 @pytest.mark.parametrize("case", [(32, 32, 128, 0, 128, 0), (100, 32, 128, 0, 128, 0), (25, 16, 64, 64, 256, 0), (8, 64, 32, 0, 64, 0),
                                   (8, 8, 128, 0, 128, 0), (16, 4, 64, 64, 256, 0), (4, 4, 512, 0, 512, 0),
                                   (8, 8, 96, 0, 128, 1), (12, 16, 256, 0, 128, 1),
-                                  (100, 8, 256, 0, 256, 0)])               # 8x8 maps with enough tiles: two images per 128-pixel tile
+                                  (100, 8, 256, 0, 256, 0),                # 8x8 maps with enough tiles: two images per 128-pixel tile
+                                  (100, 32, 128, 0, 8, 0), (128, 16, 64, 64, 24, 0)])   # the net's last convolution: a partly filled 32-channel tile
 def test_conv_halo_split_products(case):
     """fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (mdm_gemm_desc.B_split, conv_halo_body<..., SPLIT>): every
     halo tile shape, two sources, folded upsample, the sampler's 100-image batch.  Against an fp64 convolution the split path must stay
@@ -311,7 +312,7 @@ def test_f32_split_register_staged(case):
 
 
 @pytest.mark.parametrize("case", [(100, 16, 256, 256, 256), (100, 32, 256, 128, 128), (100, 8, 256, 0, 768), (100, 8, 256, 0, 256),
-                                  (8, 8, 128, 128, 256), (2, 8, 64, 0, 64), (6, 8, 32, 0, 128)])
+                                  (8, 8, 128, 128, 256), (2, 8, 64, 0, 64), (6, 8, 32, 0, 128), (100, 4, 256, 256, 256), (9, 4, 64, 0, 64)])
 def test_lin_split_products(case):
     """lin_split_kernel: 1x1 convolutions (skip projections over a concat, attention projections) with split products -- both channel
     tiles, one and two sources, bias + residual: within 2e-5 of fp64, and not the exact kernel's bits."""
@@ -333,6 +334,35 @@ def test_lin_split_products(case):
     for tag, wsplit in (("exact", None), ("split", Ps)):
         out = torch.full((N, H, H, Cout), float("nan"), device=_dev())
         ops.conv_fwd(0, geom, s0, s1, P, b.to(_dev()), out, resid=_nhwc(res).to(_dev()), w_split=wsplit)
+        torch.cuda.synchronize()
+        outs[tag] = out
+    e_exact, e_split = _relerr(outs["exact"], _nhwc(y)), _relerr(outs["split"], _nhwc(y))
+    assert e_exact < 1e-6, e_exact
+    assert e_split < 2e-5, e_split
+    assert not torch.equal(outs["exact"], outs["split"]), "B_split was ignored: lin_split_kernel did not run"
+
+
+@pytest.mark.parametrize("case", [(100, 32, 128, 0, 128), (100, 16, 256, 0, 256), (100, 8, 256, 0, 256), (5, 8, 32, 32, 64), (7, 16, 64, 0, 192)])
+def test_lin_split_stride2_and_tails(case):
+    """lin_split_kernel on the SamePad2d + stride-2 3x3 convolutions (unet6.py:257-272: taps as pixel offsets with a validity bit per row)
+    and on pixel counts that are not a multiple of the 128-row tile."""
+    from mdm import ops
+    N, H, C0, C1, Cout = case
+    C = C0 + C1
+    g = torch.Generator().manual_seed(N + H + C + Cout)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)).double(), w.double(), b.double(), stride=2).float()
+    geom = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=C1, Cout=Cout, stride=2, pad_t=0, pad_l=0, pad_b=1, pad_r=1)
+    xh = _nhwc(x)
+    s0 = xh[..., :C0].contiguous().to(_dev())
+    s1 = xh[..., C0:].contiguous().to(_dev()) if C1 else None
+    P, Ps = _split_shadow(_w_tap(w))
+    outs = {}
+    for tag, wsplit in (("exact", None), ("split", Ps)):
+        out = torch.full(tuple(_nhwc(y).shape), float("nan"), device=_dev())
+        ops.conv_fwd(0, geom, s0, s1, P, b.to(_dev()), out, w_split=wsplit)
         torch.cuda.synchronize()
         outs[tag] = out
     e_exact, e_split = _relerr(outs["exact"], _nhwc(y)), _relerr(outs["split"], _nhwc(y))
