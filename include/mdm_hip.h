@@ -382,8 +382,9 @@ int mdm_transpose_shadow_bf16(const void* Pb, void* PT, const int64_t* tiles, in
 /* The B_split shadow of fp32 filters (mdm_gemm_desc.B_split): for each of the `nseg` segments (off, len) of the device table `segs`
  * (element offsets into P / Ps; off % 4 == 0, len % 32 == 0; a segment is a run of filter rows whose length is a multiple of 32),
  * every 32-element block b of the segment becomes 128 bytes at the same offset of Ps: 16-byte chunk g (g = 0..3) = the bf16 hi halves
- * of elements {4g..4g+3, 16+4g..16+4g+3} of the block, chunk 4+g = their bf16 lo halves (hi = bf16(x), lo = bf16(x - hi), both
- * round-to-nearest-even) -- the arrangement the split halo kernel makes of its input rows in LDS.  Replaces nothing upstream: it is
+ * of elements {4g..4g+3, 16+4g..16+4g+3} of the block -- 32-bit word k of the chunk = (element 4g+k in the low half, element 16+4g+k in
+ * the high half) --, chunk 4+g = their bf16 lo halves in the same order (hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even):
+ * the arrangement the split kernels make of their input rows in LDS.  Replaces nothing upstream: it is
  * how the fp32 `F.conv2d` of unet6.py:232-235 reaches the bf16 MFMA pipe at ~fp32 accuracy. */
 int mdm_split_shadow(const float* P, float* Ps, const int64_t* segs, int nseg, void* stream);
 int mdm_fill_f32(float* p, float v, int64_t n, void* stream);

@@ -2517,14 +2517,21 @@ __device__ __forceinline__ void halo_mma_split(f32x4 (&acc)[MI][NI], const f32x4
 }
 // One 16-byte chunk pair (8 fp32 values: chunks c and c ^ 4 of a 128-byte row) -> 8 bf16 hi halves in the first chunk, 8 bf16 lo halves
 // in the second, both round-to-nearest: hi = bf16(x), lo = bf16(x - hi) (the difference is exact in fp32), |x - hi - lo| <= 2^-16 |x|.
+// Dword e of the hi (lo) chunk holds element e of the FIRST chunk in its low half and element e of the SECOND chunk in its high half: the
+// order of the 8 k inside a fragment is free as long as both operands agree (mdm_split_shadow writes the filters the same way), and this
+// one is what v_cvt_pk_bf16_f32 produces -- 6 VALU operations per two elements, no re-interleaving (the element-order version compiled
+// to 46 per chunk pair, twice the time of the whole split pass).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2_t));
+}
 __device__ __forceinline__ void split_bf16_pair(f32x4& a, f32x4& b) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t h[4], l[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bf16_t h0 = f2bf(x[2 * k]), h1 = f2bf(x[2 * k + 1]);
-        h[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        l[k] = (uint32_t)f2bf(x[2 * k] - bf2f(h0)) | ((uint32_t)f2bf(x[2 * k + 1] - bf2f(h1)) << 16);
+    for (int e = 0; e < 4; ++e) {
+        h[e] = cvt_pk_bf16(a[e], b[e]);
+        l[e] = cvt_pk_bf16(a[e] - __uint_as_float(h[e] << 16), b[e] - __uint_as_float(h[e] & 0xffff0000u));
     }
     a = (f32x4){__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3])};
     b = (f32x4){__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3])};

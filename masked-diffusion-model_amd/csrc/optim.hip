@@ -96,20 +96,21 @@ __global__ __launch_bounds__(256) void transpose_shadow_bf16_kernel(const bf16_t
 }
 
 // The split shadow of fp32 filters (mdm_gemm_desc.B_split; conv_halo_body<..., SPLIT>): per 32-element block, chunk g = 8 bf16 hi
-// halves of elements {4g..4g+3, 16+4g..16+4g+3}, chunk 4+g = their lo halves.  One thread per (block, g): two 16-byte loads, two stores.
+// halves of elements {4g..4g+3, 16+4g..16+4g+3} -- dword k = (element 4g+k, element 16+4g+k) --, chunk 4+g = their lo halves in the same
+// order.  One thread per (block, g): two 16-byte loads, two stores.
 // segs[i] = {element offset, length}; blockIdx.y = segment.
 __global__ __launch_bounds__(256) void split_shadow_kernel(const float* P, float* Ps, const int64_t* segs) {
     const int64_t off = segs[2 * blockIdx.y], len = segs[2 * blockIdx.y + 1];
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < len / 8; id += (int64_t)gridDim.x * 256) {
         const int64_t base = off + (id >> 2) * 32 + (id & 3) * 4;
         const float4 a = *reinterpret_cast<const float4*>(P + base), b = *reinterpret_cast<const float4*>(P + base + 16);
-        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float xa[4] = {a.x, a.y, a.z, a.w}, xb[4] = {b.x, b.y, b.z, b.w};
         uint32_t h[4], l[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bf16_t h0 = f2bf(x[2 * k]), h1 = f2bf(x[2 * k + 1]);
+        for (int k = 0; k < 4; ++k) {            // dword k: element k of the first chunk (low half) | element k of the second (high half)
+            const bf16_t h0 = f2bf(xa[k]), h1 = f2bf(xb[k]);
             h[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            l[k] = (uint32_t)f2bf(x[2 * k] - bf2f(h0)) | ((uint32_t)f2bf(x[2 * k + 1] - bf2f(h1)) << 16);
+            l[k] = (uint32_t)f2bf(xa[k] - bf2f(h0)) | ((uint32_t)f2bf(xb[k] - bf2f(h1)) << 16);
         }
         *reinterpret_cast<uint4*>(Ps + base) = make_uint4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<uint4*>(Ps + base + 16) = make_uint4(l[0], l[1], l[2], l[3]);

@@ -221,15 +221,15 @@ def _split_shadow(w_tap):
 
 
 def test_split_shadow_layout():
-    """mdm_split_shadow: per 32-element block, chunk g = bf16(x) of elements {4g..4g+3, 16+4g..16+4g+3}, chunk 4+g = bf16(x - hi);
-    hi + lo reproduces x to 2^-16."""
+    """mdm_split_shadow: per 32-element block, chunk g = bf16(x) of elements {4g..4g+3, 16+4g..16+4g+3} (32-bit word k = element 4g+k |
+    element 16+4g+k), chunk 4+g = bf16(x - hi) in the same order; hi + lo reproduces x to 2^-16."""
     g = torch.Generator().manual_seed(5)
     w = torch.randn(2, 8, 64, generator=g) * torch.logspace(-6, 3, 64)
     P, Ps = _split_shadow(w)
     torch.cuda.synchronize()
     halves = Ps.cpu().view(torch.int16).view(-1, 8, 8)               # [block][chunk][8 halves]
     x = w.reshape(-1, 32)
-    idx = torch.tensor([[4 * gq + j if j < 4 else 16 + 4 * gq + j - 4 for j in range(8)] for gq in range(4)])
+    idx = torch.tensor([[4 * gq + j // 2 if j % 2 == 0 else 16 + 4 * gq + j // 2 for j in range(8)] for gq in range(4)])
     xs = x[:, idx]                                                   # [block][g][8]
     hi = halves[:, :4].view(torch.bfloat16).float()
     lo = halves[:, 4:].view(torch.bfloat16).float()
