@@ -148,12 +148,13 @@ class Tester:
         total = torch.empty(0, a.out_channel, a.data_size, a.data_size)
         self.num_total_unique_images = []
         self.nearest_idx = []
-        net = self.model.with_batch(self.Sampler.local_sample_num()).eval()
         for _ in range(max_rounds):
             if len(total) >= a.data_subset_num:
                 break
             self.ema_model.store(None)
             self.ema_model.copy_to(None)
+            # (the plan is fetched behind copy_to: a bf16 model's sampling plan copies the weights it finds; see Trainer)
+            net = self.model.sampling_plan(self.Sampler.local_sample_num(), getattr(a, "sample_precision", "f32_split")).eval()
             generated, _ = self.Sampler.sample(net, self.timesteps_used_epoch)
             self.ema_model.restore(None)
             uniq = remove_duplicates_in_batches(generated, self.cosine_similarity_th)

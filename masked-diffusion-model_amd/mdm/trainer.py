@@ -125,7 +125,9 @@ class Trainer:
         a = self.args
         self.ema_model.store(None)
         self.ema_model.copy_to(None)
-        net = self.model.with_batch(self.Sampler.local_sample_num()).eval()      # this rank's share of sample_num
+        # this rank's share of sample_num, on the sampler of record (fp32 storage, split products) unless args.sample_precision says
+        # otherwise: a bf16 model's own plan is 1e-2 away from the reference sampler after 100 steps
+        net = self.model.sampling_plan(self.Sampler.local_sample_num(), getattr(a, "sample_precision", "f32_split")).eval()
         sample_0, _hist = self.Sampler.sample(net, self.timesteps_used_epoch)    # gathered: [sample_num, C, H, W] on every rank
         self.ema_model.restore(None)
         self.model.train()

@@ -162,13 +162,6 @@ class UNet2D(UNet):
     def _default_params(self, seed):
         return default_init_params(self.reference_shapes(), seed)
 
-    def with_batch(self, N):
-        if N == self.N:
-            return self
-        plans = self.__dict__.setdefault("_batch_plans", {})
-        if N not in plans:
-            plans[N] = UNet2D(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph)
-        return plans[N]
 
     def reference_param_order(self):
         """Registration order of diffusers' UNet2DModel as published: conv_in, time_embedding, down_blocks, up_blocks,

@@ -110,6 +110,29 @@ def test_unet32_preset_forward_split_products(golden, n):
     assert _rel(ys2, ye2.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_sampling_plan_follows_the_models_weights(dt):
+    """UNet.sampling_plan: the reverse sampler's plan (fp32 storage, split products by default) carries the model's CURRENT fp32 master
+    weights -- shared store for an fp32 model, a device copy into a second fp32 store for a bf16 model -- also after they change."""
+    from mdm import unet as U
+    from oracle.unet_ref import random_params
+    cfg = dict(TINY, hid_channels=64)
+    g = torch.Generator().manual_seed(11)
+    x, t = torch.randn(3, 3, 16, 16, generator=g), torch.tensor([3.0, 400.0, 999.0])
+    model = U.UNet(cfg, N=2, H=16, W=16, dtype=dt, params=random_params(cfg, 21))
+    for seed in (21, 22):
+        if seed != 21:
+            model.load_state_dict(random_params(cfg, seed))
+        want = U.UNet(cfg, N=3, H=16, W=16, dtype=0, params=model.state_dict()).eval()(x, t).sample.clone()
+        for prec, tol in (("f32_split", 2e-5), ("f32", 2e-6)):
+            plan = model.sampling_plan(3, prec).eval()
+            assert plan.dt == 0 and plan.N == 3 and plan.split_products == (prec == "f32_split")
+            got = plan(x, t).sample.clone()
+            torch.cuda.synchronize()
+            assert _rel(got, want.cpu()) < tol, (seed, prec, _rel(got, want.cpu()))
+    assert model.sampling_plan(2, "model") is model
+
+
 def test_state_dict_roundtrip_and_fresh_init():
     from mdm import unet as U
     from oracle.unet_ref import param_shapes, random_params
