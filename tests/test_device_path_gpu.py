@@ -176,7 +176,10 @@ def test_sampler_250_steps_rel_l2_vs_oracle(dt, bound, T):
 
 
 @pytest.mark.parametrize("dt,dep,mode,T", [(0, "independent", "base_momentum", 1000), (1, "independent", "base_momentum", 1000),
-                                            (0, "dependent_prev", "base_sampling", 200)])
+                                            (0, "dependent_prev", "base_sampling", 200),
+                                            # fp32 storage, convolution products as bf16 hi / lo pairs (UNet(f32_products="split"), the
+                                            # sampler of record since DESIGN finding 31): the SAME bars as exact fp32
+                                            ("split", "independent", "base_momentum", 1000)])
 def test_sampler_1000_steps_teacher_forced_vs_oracle(dt, dep, mode, T):
     """EVERY one of the 1000 reverse steps of cfg2's schedule against the oracle's: the HIP loop starts each step from the
     oracle's x_t of that step (Sampler.step_hook), both consume the host RNG in the reference's order, and x0_hat, both
@@ -202,7 +205,9 @@ def test_sampler_1000_steps_teacher_forced_vs_oracle(dt, dep, mode, T):
         _ORACLE_RUNS[("forced", dep, mode, T)] = dict(zip(mdm.sampler.HISTORY_NAMES, ref))
     ref = _ORACLE_RUNS[("forced", dep, mode, T)]
     ref_xt = ref["sample_t"].cuda()
-    model = mdm.UNet(TINY, N=n, H=hw, W=hw, dtype=dt, params=params).eval()
+    products, tag = ("split", "f32_split") if dt == "split" else ("exact", "f32" if dt == 0 else "bf16")
+    dt = 0 if dt == "split" else dt
+    model = mdm.UNet(TINY, N=n, H=hw, W=hw, dtype=dt, params=params, f32_products=products).eval()
     s = mdm.Scheduler(a)
     s.update_ddpm_num_steps(T)
     smp = mdm.Sampler(None, a, s, [None] * 3)
@@ -223,7 +228,7 @@ def test_sampler_1000_steps_teacher_forced_vs_oracle(dt, dep, mode, T):
         scale = torch.maximum(r.norm(dim=1), ref["sample_0"][1:upto + 1].double().flatten(1).norm(dim=1) * 1e-3)
         e = (h - r).norm(dim=1) / scale
         worst[key] = (float(e.max()), float(e.median()))
-    _note("sampler_1000_teacher_forced", dict(dtype="f32" if dt == 0 else "bf16", dep=dep, mode=mode, steps=T, n=n,
+    _note("sampler_1000_teacher_forced", dict(dtype=tag, dep=dep, mode=mode, steps=T, n=n,
                                               worst_and_median_rel_l2_per_step=worst))
     for key, (mx, med) in worst.items():
         if dt == 0:
