@@ -301,8 +301,9 @@ def bench_config(mdm, _lib, TrainStep, name, dev, opt_):
     log(f"{name}: {ms:.3f} ms/step, family {tf:.0f} TFLOP/s")
     if name == "cfg5":
         a.sample_num = 100
-        for tag, sdt in (("bf16", mdm.BF16), ("f32", mdm.F32)):
-            net = (model.with_batch(100) if sdt == dt else mdm.UNet(cfg, N=100, H=H, W=H, dtype=sdt, seed=0)).eval()
+        # "f32_split" = the sampler of record (fp32 storage, convolution products as bf16 hi / lo pairs): the model's own sampling plan
+        for tag in ("bf16", "f32_split", "f32"):
+            net = (model.with_batch(100) if tag == "bf16" else model.sampling_plan(100, tag)).eval()
             smp = mdm.Sampler(None, a, sched, [None] * 3)
             smp.sample(net, used[:3])
             torch.cuda.synchronize()
