@@ -2548,7 +2548,7 @@ __device__ __forceinline__ void split_bf16_pair(f32x4& a, f32x4& b) {
 // 128-byte row becomes the 8 hi halves, chunk g ^ 4 the 8 lo halves of the same 8 channels: the fragment addresses do not change),
 // and the filter tiles arrive already split from the B_split shadow (mdm_split_shadow: same bytes, same arrangement).
 template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t, bool SPLIT = false>
-__device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
+__device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx, const int m_base = 0) {
     static_assert(!SPLIT || sizeof(T) == 4, "conv_halo: SPLIT is the fp32-storage variant");
     constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
     constexpr int NG = 9 / TG;                                    // groups per channel slab
@@ -2587,7 +2587,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     // instead of eight.  No effect on time at cfg2 (the loop is bound by the CU's intake, not by L2 misses); it is there
     // for the L2-side traffic (FETCH_SIZE), which counts every XCD's own fetch of the same line.
     const int bid = xcd_remap(bx, gx);
-    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
+    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = m_base + mt * BM;   // (m_base: conv_halo_mixed_kernel)
     const int img = m0 >> p_sh, y0 = (m0 >> ow_sh) & (OH - 1);
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int NCS = d.Ck / KC;                       // channel slabs over both sources
@@ -2782,6 +2782,16 @@ template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     conv_halo_body<BM, NPW, BN, NSB, TG, T, SPLIT>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two tile sizes in one launch (split products, sample_num = 100): a 32x32 layer is 800 tiles of 256 pixels on 256 CUs -- 3.1 rounds of
+// work in 4 rounds of workgroups, the last one on 32 CUs.  Here the first `n_big` workgroups take whole rounds of 256-pixel tiles and
+// the rest of the pixels go out as 128-pixel tiles (0.6 of a big tile's time) behind them: 3 rounds + a short one.
+template <int NPW_A, int NSB_A, int NPW_B, int NSB_B>
+__global__ __launch_bounds__(512) void conv_halo_mixed_kernel(mdm_gemm_desc d, int n_big, int m_split) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    if ((int)blockIdx.x < n_big) conv_halo_body<256, NPW_A, 64, NSB_A, 3, float, true>(d, lds, (int)blockIdx.x, n_big);
+    else conv_halo_body<128, NPW_B, 64, NSB_B, 3, float, true>(d, lds, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, m_split);
 }
 
 // ----------------------------------------------------------------------------
@@ -3175,6 +3185,33 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
 // The split-products variant is not MFMA-bound: per flop a 256-pixel tile reads 2/3 of the LDS fragment bytes and streams half the
 // filter bytes of a 128-pixel one (stamps: 893 cycles per tap on 128 pixels; the 16x16 layers on 256-pixel tiles run the same flops in
 // 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
+// conv_halo_mixed_kernel: whole rounds of 256-pixel tiles, the remainder as 128-pixel tiles -- taken when the remainder is at most one
+// round of small tiles (otherwise two short rounds cost more than the one long round they replace).  0 = plain launch.
+#ifndef MDM_SPLIT_MIXED
+#define MDM_SPLIT_MIXED 1
+#endif
+static int launch_halo_mixed(const mdm_gemm_desc& d, hipStream_t s) {
+    const int tn = d.N / 64;
+    const int64_t tiles = (int64_t)(d.M / 256) * tn;
+    const int64_t big_m = (tiles / 256) * 256 / tn;                // M tiles of 256 pixels in whole rounds (all their channel tiles)
+    const int64_t rest = (d.M / 256 - big_m) * 2 * tn;             // 128-pixel tiles behind them
+    if (!MDM_SPLIT_MIXED || d.OW != 32 || d.OH % 8 || big_m < 1 || rest < 1 || rest > 256 || tiles % 256 == 0) return -2;
+    const int npa = halo_pieces(256, d.OH, d.OW), npb = halo_pieces(128, d.OH, d.OW);
+    if (npa > 48 || npb > 32) return -2;
+    int bytes = std::max(2 * npa * 1024 + 2 * 3 * 64 * 128 + 1024, 2 * npb * 1024 + 3 * 3 * 64 * 128 + 1024);
+    bytes = std::max(bytes, 256 * 64 * 4);
+    MDM_REQUIRE(bytes <= 160 * 1024, "conv_halo_mixed: tile does not fit (%d bytes)", bytes);
+    static int configured = 0;
+    if (configured < bytes) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_mixed_kernel<6, 2, 4, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = bytes;
+    }
+    hipLaunchKernelGGL((conv_halo_mixed_kernel<6, 2, 4, 3>), dim3((unsigned)(big_m * tn + rest)), dim3(512), bytes, s, d, (int)(big_m * tn),
+                       (int)(big_m * 256));
+    return 0;
+}
+
 // The LAST convolution of the net (128 -> 3, padded to 8 output channels; unet6.py:505) with split products: on the register-staged
 // kernel its 64-wide tiles were 8 real channels each and it took 172 us of the reverse step -- more than a 128 -> 128 layer.  On the
 // 256-pixel halo tiles with a 32-channel tile (one 16-wide MFMA column per wave, rows beyond N zero): 0 = not eligible, else 256.
@@ -3439,7 +3476,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             // fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (conv_halo_body<..., SPLIT>)
             const int hb32 = halo_tile_f32_split(d, hb32_exact);
             const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
-            if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, MDM_SPLIT_NSB256, 64, float, true>(d, s) : launch_halo<256, 6, MDM_SPLIT_NSB256, 64, float, true>(d, s);
+            if (hb32 == 256 && (rc = launch_halo_mixed(d, s)) != -2) { /* whole rounds of 256-pixel tiles + a short round of 128-pixel ones */ }
+            else if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, MDM_SPLIT_NSB256, 64, float, true>(d, s) : launch_halo<256, 6, MDM_SPLIT_NSB256, 64, float, true>(d, s);
             else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float, true>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float, true>(d, s)
                                                                                              : launch_halo<128, 6, 3, 64, float, true>(d, s);
             else if ((int64_t)(d.M / 64) * (d.N / 64) < kBigMinTiles && d.N % 32 == 0)
