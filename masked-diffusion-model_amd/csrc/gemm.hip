@@ -2474,8 +2474,8 @@ template <int NPW, int APT, int NG> constexpr int halo_a_count(int g) {         
     const int t = ((g % NG) + NG) % NG;
     return t * APT >= NPW ? 0 : (NPW - t * APT < APT ? NPW - t * APT : APT);
 }
-template <int NPW, int APT, int D, int TG> constexpr int halo_vmcnt(int g) {      // DMA operations younger than group g's filter tiles
-    int n = (D - 1) * TG;
+template <int NPW, int APT, int D, int TG, int GBW = 1> constexpr int halo_vmcnt(int g) {      // DMA operations younger than group g's filter tiles
+    int n = (D - 1) * TG * GBW;                                 // (GBW filter pieces per wave and tap: 2 on 128-channel tiles)
     for (int j = 1; j <= D; ++j) n += halo_a_count<NPW, APT, 9 / TG>(g - j);
     return n;
 }
@@ -2557,10 +2557,14 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     static_assert(9 % TG == 0 && D >= 1 && D < NG && APT * (NG - D) >= NPW, "conv_halo: halo pieces do not fit in front of the refill distance");
     static_assert(MI >= 1 && NI >= 1, "conv_halo: tile too small for 4 x 2 waves");
     constexpr int B_BYTES = BN * 128, STAGE_B = TG * B_BYTES;
+    constexpr int GBW = BN > 64 ? BN / 64 : 1;                    // filter pieces (8 rows of 128 B) per wave and tap
+    static_assert(BN <= 64 || BN % 64 == 0, "conv_halo: channel tiles above 64 in steps of 64");
     // DMA operations a wave issues behind the last halo piece of a slab up to the barrier of the slab's last group: the filter
     // tiles of the groups in between (the pieces go out in groups 0 .. (NPW - 1) / APT, behind that group's own filter tiles)
-    constexpr int SPLIT_WAIT = (NG - 2 - (NPW - 1) / APT) * TG;
-    static_assert(!SPLIT || (SPLIT_WAIT >= 0 && SPLIT_WAIT <= halo_vmcnt<NPW, APT, D, TG>(NG - 1)), "conv_halo: split schedule");
+    constexpr int SPLIT_HALO = (NG - 2 - (NPW - 1) / APT) * TG * GBW;
+    static_assert(!SPLIT || SPLIT_HALO >= 0, "conv_halo: split schedule");
+    constexpr int LAST_NORMAL = halo_vmcnt<NPW, APT, D, TG, GBW>(NG - 1);      // that barrier's own count (its filter tiles have landed)
+    constexpr int SPLIT_WAIT = SPLIT_HALO < LAST_NORMAL ? SPLIT_HALO : LAST_NORMAL;
     constexpr int KC = 128 / (int)sizeof(T);                    // channels per slab (one 128-byte halo row)
     constexpr bool F32 = sizeof(T) == 4;
     typedef typename std::conditional<F32, f32x4, bf16x8>::type Frag;
@@ -2624,6 +2628,9 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     auto issue_b = [&](int tap, int cs, int lds_off) {               // lds_off: byte offset of the tile inside the ring
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * KC) * (int64_t)sizeof(T);
         lds_dma16((cs < NCS && b_live) ? b_row + off : zlane, b_wave ? bring + lds_off + wave * 1024 : dummy);
+#pragma unroll
+        for (int q = 1; q < GBW; ++q)                                // 128-channel tiles: rows 64 q + 8 wave .. of the tile (N % BN == 0 there)
+            lds_dma16(cs < NCS ? b_row + off + (int64_t)q * 64 * d.ldb * (int64_t)sizeof(T) : zlane, bring + lds_off + (wave + 8 * q) * 1024);
     };
 
     // ---- prologue: halo of slab 0, filter tiles of tap-slabs 0..D-1 (in flight while the offset tables below are built)
@@ -2634,21 +2641,35 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 #pragma unroll
         for (int k = 0; k < TG; ++k) issue_b((u % NG) * TG + k, u / NG, u * STAGE_B + k * B_BYTES);
 
-    // ---- per-lane fragment offsets
-    int a_addr[9][MI];
+    // ---- per-lane fragment offsets: a table of 9 x MI addresses -- or, on the tiles whose accumulators and fragments leave no room for
+    // it (128 channels: 16 accumulator tiles per wave; the table cost 36 registers and the kernel spilled), the MI halo rows of the
+    // centre tap only, the tap's row shift and the swizzle being four VALU operations per address under 48 MFMAs per tap
+    constexpr bool A_TABLE = MI * NI < 16;
+    int a_addr[A_TABLE ? 9 : 1][MI];
+    int a_hb[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = wr * WM + i * 16 + (lane & 15);
         const int il = ml >> rows_sh, mrem = ml - (il << rows_sh);
         const int r = mrem >> ow_sh, x = mrem - (r << ow_sh);
         const int hb = il * HRI + (r + 1) * HW2 + x + 1;
+        a_hb[i] = hb;
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
+        for (int tp = 0; tp < (A_TABLE ? 9 : 1); ++tp) {
             const int ty = tp / 3, tx = tp - ty * 3;
             const int hr = hb + sgn * (ty - 1) * HW2 + sgn * (tx - 1);
             a_addr[tp][i] = hr * 128 + (((lane >> 4) ^ (hr & 7)) << 4);
         }
     }
+    const int lane_g = lane >> 4;
+    auto a_at = [&](int tp, int i) -> int {                         // tp is a constant after unrolling
+        if constexpr (A_TABLE) return a_addr[tp][i];
+        else {
+            const int ty = tp / 3, tx = tp - ty * 3;
+            const int hr = a_hb[i] + sgn * ((ty - 1) * HW2 + (tx - 1));
+            return hr * 128 + ((lane_g ^ (hr & 7)) << 4);
+        }
+    };
     int b_off[2][NI];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -2687,7 +2708,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
         }
     };
     if constexpr (SPLIT) {                 // slab 0: its pieces are older than the D * TG filter tiles of the prologue
-        wait_vmcnt<D * TG>();
+        wait_vmcnt<D * TG * GBW>();
         __builtin_amdgcn_s_barrier();
         split_halo(lds);
     }
@@ -2704,7 +2725,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
                the split's LDS writes are complete before the barrier that opens the next slab */                 \
             MDM_T(const unsigned long long tw0 = stamp_now();)                                                   \
             if (SPLIT && (T) / TG == NG - 1) wait_vmcnt<SPLIT_WAIT>();                                           \
-            else wait_vmcnt<halo_vmcnt<NPW, APT, D, TG>((T) / TG)>();                                            \
+            else wait_vmcnt<halo_vmcnt<NPW, APT, D, TG, GBW>((T) / TG)>();                                       \
             if (SPLIT && (T) == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            \
             MDM_T(const unsigned long long tw1 = stamp_now(); t_wait += tw1 - tw0;)                              \
             __builtin_amdgcn_s_barrier();                                                                        \
@@ -2728,25 +2749,27 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                       \
                 bfr[ks][j] = *reinterpret_cast<const Frag*>(Bs + b_off[ks][j]);                                  \
-        if ((T) == 0) {            /* a new halo buffer: its fragments can only be read behind this barrier */   \
+        if ((T) == 0 || !A_TABLE) { /* a new halo buffer: its fragments can only be read behind this barrier (no table = no   \
+                                       second fragment set either: this tap's fragments are fetched at its top) */       \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-                    afr[0][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[0][i] ^ (ks << 6)));             \
+                    afr[A_TABLE ? 0 : AF(T)][ks][i] = *reinterpret_cast<const Frag*>(As + (a_at((T), i) ^ (ks << 6))); \
         }                                                                                                        \
-        if constexpr (SPLIT) halo_mma_split<MI, NI>(acc, bfr[0], afr[(T) & 1][1]);      /* b.hi x a.lo */       \
-        else halo_mma_tile<MI, NI>(acc, bfr[0], afr[(T) & 1][0]);                                                \
-        if ((T) < 8) {             /* the next tap reads the SAME halo buffer at shifted rows: fetch it now */    \
+        if constexpr (SPLIT) halo_mma_split<MI, NI>(acc, bfr[0], afr[AF(T)][1]);        /* b.hi x a.lo */       \
+        else halo_mma_tile<MI, NI>(acc, bfr[0], afr[AF(T)][0]);                                                  \
+        if ((T) < 8 && A_TABLE) {  /* the next tap reads the SAME halo buffer at shifted rows: fetch it now */    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
-                    afr[((T) + 1) & 1][ks][i] = *reinterpret_cast<const Frag*>(As + (a_addr[((T) + 1) % 9][i] ^ (ks << 6))); \
+                    afr[AF((T) + 1)][ks][i] = *reinterpret_cast<const Frag*>(As + (a_at(((T) + 1) % 9, i) ^ (ks << 6))); \
         }                                                                                                        \
         if constexpr (SPLIT) {                                                                                   \
-            halo_mma_split<MI, NI>(acc, bfr[1], afr[(T) & 1][0]);                       /* b.lo x a.hi */       \
-            halo_mma_split<MI, NI>(acc, bfr[0], afr[(T) & 1][0]);                       /* b.hi x a.hi */       \
-        } else halo_mma_tile<MI, NI>(acc, bfr[1], afr[(T) & 1][1]);                                              \
+            halo_mma_split<MI, NI>(acc, bfr[1], afr[AF(T)][0]);                         /* b.lo x a.hi */       \
+            halo_mma_split<MI, NI>(acc, bfr[0], afr[AF(T)][0]);                         /* b.hi x a.hi */       \
+        } else halo_mma_tile<MI, NI>(acc, bfr[1], afr[AF(T)][1]);                                                \
         if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
-    Frag afr[2][2][MI];                    // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
+#define AF(T) (A_TABLE ? ((T) & 1) : 0)
+    Frag afr[A_TABLE ? 2 : 1][2][MI];      // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
     MDM_T(unsigned long long t_wait = 0, t_bar = 0, t_split = 0;)
     MDM_T(const unsigned long long tstart = stamp_now();)
     for (int cs = 0; cs < NCS; ++cs) {
@@ -2755,6 +2778,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
         a_cur = a_cur == 0 ? ABUF : 0;
     }
 #undef MDM_HALO_TAP
+#undef AF
     wait_vmcnt<0>();
     MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
@@ -3114,9 +3138,8 @@ static int halo_pieces(int bm, int OH, int OW) {           // 1-KiB pieces of on
     const int imgs = bm > OH * OW ? bm / (OH * OW) : 1, R = imgs > 1 ? OH : bm / OW;
     return (imgs * (R + 2) * (OW + 2) + 7) / 8;
 }
-template <int BM, int NPW, int NSB, int BN = 64, typename T = bf16_t, bool SPLIT = false>
-static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // one filter row (3 taps) per barrier
-    constexpr int TG = 3;
+template <int BM, int NPW, int NSB, int BN = 64, typename T = bf16_t, bool SPLIT = false, int TG = 3>
+static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // TG = 3: one filter row (3 taps) per barrier
     const int NPA = halo_pieces(BM, d.OH, d.OW);
     int bytes = 2 * NPA * 1024 + NSB * TG * BN * 128 + 1024;
     if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
@@ -3187,6 +3210,9 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
 // 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
 // conv_halo_mixed_kernel: whole rounds of 256-pixel tiles, the remainder as 128-pixel tiles -- taken when the remainder is at most one
 // round of small tiles (otherwise two short rounds cost more than the one long round they replace).  0 = plain launch.
+#ifndef MDM_SPLIT_BN128
+#define MDM_SPLIT_BN128 160         // 128-channel split tiles when the layer has at least this many of them (0: never)
+#endif
 #ifndef MDM_SPLIT_MIXED
 #define MDM_SPLIT_MIXED 1
 #endif
@@ -3476,6 +3502,13 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             // fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (conv_halo_body<..., SPLIT>)
             const int hb32 = halo_tile_f32_split(d, hb32_exact);
             const int npw = (halo_pieces(hb32, d.OH, d.OW) + 7) / 8;
+            // 256 pixels x 128 channels (one tap per barrier, four filter stages): the halo is staged and split once for twice the
+            // channels and a wave multiplies 4 x 4 fragments per tap -- 16 fragment reads for 48 MFMAs where the 64-channel tile reads
+            // 12 for 24; half as many tiles, so a 16x16 layer at sample_num = 100 is ONE round of workgroups instead of 1.56 in two
+            if (hb32 == 256 && MDM_SPLIT_BN128 && d.N % 128 == 0 && (d.OW == 16 || d.OW == 32) &&
+                (int64_t)(d.M / 256) * (d.N / 128) >= MDM_SPLIT_BN128) {
+                rc = npw <= 4 ? launch_halo<256, 4, 4, 128, float, true, 1>(d, s) : launch_halo<256, 6, 4, 128, float, true, 1>(d, s);
+            } else
             if (hb32 == 256 && (rc = launch_halo_mixed(d, s)) != -2) { /* whole rounds of 256-pixel tiles + a short round of 128-pixel ones */ }
             else if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, MDM_SPLIT_NSB256, 64, float, true>(d, s) : launch_halo<256, 6, MDM_SPLIT_NSB256, 64, float, true>(d, s);
             else if (hb32 == 128) rc = npw <= 3 ? launch_halo<128, 3, 3, 64, float, true>(d, s) : npw <= 4 ? launch_halo<128, 4, 3, 64, float, true>(d, s)
