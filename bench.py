@@ -181,6 +181,14 @@ def cpu_baseline(n_steps=10, n_warm=2, parity_out=None):
     return out
 
 
+SAMPLER_MODES = {
+    "f32": "fp32 storage, exact fp32 products (v_mfma_f32_16x16x4_f32), fp32 accumulation",
+    "f32_split": "fp32 storage and accumulation; forward convolutions multiply every operand as bf16(x) + bf16(x - bf16(x)): hi*hi + hi*lo + lo*hi "
+                 "on v_mfma_f32_16x16x32_bf16 (<= 2^-16 per product); GroupNorm, attention, time embedding, scheduler kernels exact fp32",
+    "bf16": "bf16 storage, bf16 products, fp32 accumulation",
+}
+
+
 def sampler_parity(mdm, cfg, sdt, dev, pparams, ref, products="exact"):
     """-> dict of the two parity figures (see PARITY_*) for one dtype; `ref` = the oracle child's trajectory (numpy)."""
     pa = parity_args()
@@ -536,7 +544,7 @@ def main():
             sec = time.perf_counter() - t1
             nst = min(opt_.sampler_steps, len(used))
             log(f"sampler {tag}: {sec:.2f}s")
-            sampler[tag] = {"dtype": tag, "steps": nst, "sample_num": args.sample_num, "seconds": round(sec, 3),
+            sampler[tag] = {"dtype": tag, "arithmetic": SAMPLER_MODES[tag], "steps": nst, "sample_num": args.sample_num, "seconds": round(sec, 3),
                             "ms_per_step": round(1e3 * sec / nst, 3), "finite": bool(torch.isfinite(x0_hat).all())}
             del net
             par = None

@@ -243,7 +243,8 @@ def test_split_shadow_layout():
                                   (8, 8, 96, 0, 128, 1), (12, 16, 256, 0, 128, 1),
                                   (100, 8, 256, 0, 256, 0),                # 8x8 maps with enough tiles: two images per 128-pixel tile
                                   (100, 32, 128, 0, 8, 0), (128, 16, 64, 64, 24, 0),   # the net's last convolution: a partly filled 32-channel tile
-                                  (100, 16, 256, 0, 256, 0), (100, 16, 128, 128, 256, 0), (50, 32, 64, 0, 256, 1)])   # 256 x 128 tiles (one tap per barrier)
+                                  (100, 16, 256, 0, 256, 0), (100, 16, 128, 128, 256, 0), (50, 32, 64, 0, 256, 1),   # 256 x 128 tiles (one tap per barrier)
+                                  (80, 32, 64, 0, 64, 0)])                 # whole rounds of 256-pixel tiles + 128-pixel tiles in one launch
 def test_conv_halo_split_products(case):
     """fp32 storage, products as bf16 hi / lo pairs on the bf16 matrix pipe (mdm_gemm_desc.B_split, conv_halo_body<..., SPLIT>): every
     halo tile shape, two sources, folded upsample, the sampler's 100-image batch.  Against an fp64 convolution the split path must stay
