@@ -118,7 +118,8 @@ typedef struct mdm_gemm_desc {
      * With it, a 3x3 stride-1 forward convolution that qualifies for the halo kernel multiplies on the bf16 matrix pipe with fp32
      * storage and fp32 accumulation: every operand x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), a product = hi*hi + hi*lo + lo*hi
      * -- relative error <= ~2^-16 per product instead of 2^-24, at a fifth of the matrix time of the exact path.  Descriptors that do
-     * not qualify ignore it and run the exact fp32 path on B.  NULL = exact fp32 everywhere (the parity path). */
+     * not qualify ignore it and run the exact fp32 path on B.  NULL = exact fp32 everywhere (the parity path).
+     * (NaN operands stay NaN; an infinite operand becomes NaN -- Inf - bf16(Inf) is NaN -- where the exact path would give +-Inf.) */
     const void* B_split;
 } mdm_gemm_desc;
 
