@@ -3205,9 +3205,6 @@ static int halo_tile_f32(const mdm_gemm_desc& d) {
     return 0;
 }
 
-// The split-products variant is not MFMA-bound: per flop a 256-pixel tile reads 2/3 of the LDS fragment bytes and streams half the
-// filter bytes of a 128-pixel one (stamps: 893 cycles per tap on 128 pixels; the 16x16 layers on 256-pixel tiles run the same flops in
-// 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
 // conv_halo_mixed_kernel: whole rounds of 256-pixel tiles, the remainder as 128-pixel tiles -- taken when the remainder is at most one
 // round of small tiles (otherwise two short rounds cost more than the one long round they replace).  0 = plain launch.
 #ifndef MDM_SPLIT_BN128
@@ -3281,6 +3278,10 @@ static int launch_lin_split(const mdm_gemm_desc& d, hipStream_t s) {
 #ifndef MDM_SPLIT_NSB256
 #define MDM_SPLIT_NSB256 2          // filter stages of the 256-pixel split tiles
 #endif
+// The split-products variant is not MFMA-bound: per flop a 256-pixel tile reads 2/3 of the LDS fragment bytes and streams half the
+// filter bytes of a 128-pixel one (stamps: 893 cycles per tap on 128 pixels; the 16x16 layers on 256-pixel tiles run the same flops in
+// 2/3 of the time of the 32x32 layers on 128-pixel tiles).  Estimated time = rounds of workgroups x tile cost (256: 1.46 x 128).
+// (Pixel tile of the 64-channel split tiles; layers with enough 128-channel tiles take those instead, see gemm_launch.)
 static int halo_tile_f32_split(const mdm_gemm_desc& d, int exact_choice) {
     // 8x8 maps: two whole images per tile when that still gives every CU a tile (sample_num = 100, 256 channels: 400 tiles of 64
     // pixels = 1.56 rounds at 16 % of the matrix pipe inside the loop; 200 tiles of 128 pixels = one round)
