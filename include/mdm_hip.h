@@ -218,6 +218,11 @@ int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1,
  * Replaces both einsums, the softmax and `.contiguous()` of unet6.py:319-324 and their autograd backward.
  * ------------------------------------------------------------------------- */
 int mdm_attn_supported(int dtype, int L, int C);
+/* Exact-fp32 forward of the same attention for short sequences (L in {16, 32, 48, 64}, C in {64, 128, 256}: the 8x8 / 4x4 attention
+ * blocks on the fp32 path): one launch on v_mfma_f32_16x16x4_f32 instead of two batched contractions and a softmax launch.  It also
+ * writes the probabilities S[N][L][L] (fp32) -- what the unfused fp32 backward (softmax_bwd + three contractions) reads. */
+int mdm_attn_f32_small_supported(int L, int C);
+int mdm_attn_f32_small_fwd(const float* qkv, float* o, float* S, int N, int L, int C, float scale, void* stream);
 int mdm_attn_fwd(int dtype, const void* qkv, void* o, float* lse, int N, int L, int C, float scale, void* stream);
 int mdm_attn_bwd(int dtype, const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                  int N, int L, int C, float scale, void* stream);

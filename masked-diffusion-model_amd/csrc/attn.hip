@@ -509,8 +509,129 @@ static int attn_mh_dispatch(int which, int D, const void* q, const void* k, cons
     return -1;
 }
 
+// ----------------------------------------------------------------------------
+// Exact-fp32 attention FORWARD for the short sequences of the fp32 path (L <= 64: the 8x8 and 4x4 attention blocks of unet6 in the reverse
+// sampler and in fp32 training): o = softmax(q k^T * scale) v on v_mfma_f32_16x16x4_f32, one workgroup per image, one launch instead
+// of two batched contractions and a softmax launch (15 + 6.5 + 13 us per block at sample_num = 100).  The probabilities ARE written
+// (S[N][L][L], 16 KB per image at L = 64): the fp32 backward of the unfused path reads them.
+//   Orientation as in the bf16 kernels: S^T[key][query] = K Q^T -- wave w owns queries 16 w .. 16 w + 15 (the MFMA column, lane & 15) and
+//   all keys, so a query's softmax is lane-local plus two __shfl_xor over the four lane groups; the accumulator of that product
+//   (lane group g, register r = key 16 kt + 4 g + r) IS the B operand of o^T[c][query] = V^T P^T with the same "a lane's four
+//   consecutive k feed four MFMAs" convention as gemm_f32_mfma_kernel; V is staged once per image in LDS ([L][C + 4]: the four
+//   lane groups read four different rows, the pad puts them 16 banks apart) and read as scalars (A[i = c][k = key] is strided in memory).
+//   Fragments of Q (kept in registers: C / 16 float4 per lane) and K come straight from global memory.
+template <int C>
+__global__ __launch_bounds__(256) void attn_f32_small_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ S,
+                                                             int L, float scale) {
+    constexpr int NS = C / 16, VP = C + 4;
+    extern __shared__ __attribute__((aligned(16))) float vs[];             // [L][VP]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, g = lane >> 4;
+    const int n = blockIdx.x, KT = L >> 4;
+    const float* base = qkv + (int64_t)n * L * 3 * C;
+    for (int idx = t; idx < L * (C / 4); idx += 256) {                       // V -> LDS, coalesced 16-byte loads
+        const int row = idx / (C / 4), c4 = idx - row * (C / 4);
+        *reinterpret_cast<float4*>(vs + row * VP + 4 * c4) = *reinterpret_cast<const float4*>(base + (int64_t)row * 3 * C + 2 * C + 4 * c4);
+    }
+    __syncthreads();
+    if (wave >= KT) return;                                                  // (L = 16: one query tile; no barrier behind this point)
+    const int query = 16 * wave + j;
+    float4 qf[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) qf[s2] = *reinterpret_cast<const float4*>(base + (int64_t)query * 3 * C + 16 * s2 + 4 * g);
+    f32x4 st[4];                                                             // S^T tiles: keys 16 kt + 4 g + r, this lane's query
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kt < KT) {
+            const float* kr = base + (int64_t)(16 * kt + j) * 3 * C + C + 4 * g;      // A[i = key][k = c]: this lane's key row
+            f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f};             // two accumulation chains (even / odd k-steps): an MFMA waits for the one it adds to
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2 += 2) {
+                const float4 kf = *reinterpret_cast<const float4*>(kr + 16 * s2), kg = *reinterpret_cast<const float4*>(kr + 16 * s2 + 16);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[s2].x, st[kt], 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kg.x, qf[s2 + 1].x, s1, 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[s2].y, st[kt], 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kg.y, qf[s2 + 1].y, s1, 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[s2].z, st[kt], 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kg.z, qf[s2 + 1].z, s1, 0, 0, 0);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[s2].w, st[kt], 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kg.w, qf[s2 + 1].w, s1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kt][r] += s1[r];
+        }
+    }
+    // softmax over the keys of this lane's query: 4 registers x KT tiles here, the other lane groups through two shuffles
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+        if (kt < KT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][r] *= scale; mx = fmaxf(mx, st[kt][r]); }
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+        if (kt < KT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - mx); sum += st[kt][r]; }
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float* Srow = S + ((int64_t)n * L + query) * L;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+        if (kt < KT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kt][r] *= inv;
+            *reinterpret_cast<float4*>(Srow + 16 * kt + 4 * g) = make_float4(st[kt][0], st[kt][1], st[kt][2], st[kt][3]);
+        }
+    // o^T[c][query] = sum_key V^T[c][key] P^T[key][query]
+    float* orow = o + ((int64_t)n * L + query) * C;
+#pragma unroll 4
+    for (int ct = 0; ct < NS; ++ct) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};       // two chains: key tiles 0, 2 / 1, 3
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            if (kt < KT) {
+                const float* vp = vs + (16 * kt + 4 * g) * VP + 16 * ct + j;           // A[i = c = 16 ct + j][k = key 16 kt + 4 g + m]
+                f32x4& a = (kt & 1) ? acc1 : acc;
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], st[kt][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[VP], st[kt][1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[2 * VP], st[kt][2], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[3 * VP], st[kt][3], a, 0, 0, 0);
+            }
+        *reinterpret_cast<float4*>(orow + 16 * ct + 4 * g) = make_float4(acc[0] + acc1[0], acc[1] + acc1[1], acc[2] + acc1[2], acc[3] + acc1[3]);   // c = 16 ct + 4 g + r
+    }
+}
+
 }  // namespace mdm
 using namespace mdm;
+
+extern "C" int mdm_attn_f32_small_supported(int L, int C) {
+    return (L == 16 || L == 32 || L == 48 || L == 64) && (C == 64 || C == 128 || C == 256) ? 1 : 0;
+}
+extern "C" int mdm_attn_f32_small_fwd(const float* qkv, float* o, float* S, int N, int L, int C, float scale, void* stream) {
+    MDM_REQUIRE(mdm_attn_f32_small_supported(L, C), "attn_f32_small_fwd: unsupported L %d / C %d (use the contraction path)", L, C);
+    MDM_REQUIRE(qkv && o && S && N > 0, "attn_f32_small_fwd: bad arguments");
+    const int bytes = L * (C + 4) * 4;
+    hipStream_t s = pick_stream(stream);
+#define MDM_ATTN_F32(CC)                                                                                                               \
+    {                                                                                                                                  \
+        static int configured = 0;                                                                                                     \
+        if (configured < bytes) {                                                                                                      \
+            MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_small_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); \
+            configured = bytes;                                                                                                        \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((attn_f32_small_kernel<CC>), dim3((unsigned)N), dim3(256), bytes, s, qkv, o, S, L, scale);                  \
+    }
+    if (C == 64) MDM_ATTN_F32(64) else if (C == 128) MDM_ATTN_F32(128) else MDM_ATTN_F32(256)
+#undef MDM_ATTN_F32
+    return launch_status("attn_f32_small_fwd");
+}
 
 extern "C" int mdm_attn_supported(int dtype, int L, int C) {
     return dtype == MDM_BF16 && L > 0 && L % 16 == 0 && (C == 32 || C == 64 || C == 128 || C == 256) ? 1 : 0;

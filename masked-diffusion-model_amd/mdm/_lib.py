@@ -57,6 +57,8 @@ _PROTOS = {
     "mdm_groupnorm_bwd_add": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_attn_supported": ([i32, i32, i32], i32),
     "mdm_attn_fwd": ([i32, vp, vp, vp, i32, i32, i32, f32, vp], i32),
+    "mdm_attn_f32_small_supported": ([i32, i32], i32),
+    "mdm_attn_f32_small_fwd": ([vp, vp, vp, i32, i32, i32, f32, vp], i32),
     "mdm_attn_bwd": ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),
     "mdm_attn_mh_fwd": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp], i32),
     "mdm_attn_mh_bwd": ([i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp], i32),

@@ -238,6 +238,15 @@ def attn_fwd(dt, qkv, o, lse, N, L, C, scale):
     call("mdm_attn_fwd", dt, ptr(qkv), ptr(o), ptr(lse), N, L, C, float(scale), stream())
 
 
+def attn_f32_small_supported(L, C):
+    return bool(_lib.load().mdm_attn_f32_small_supported(L, C))
+
+
+def attn_f32_small_fwd(qkv, o, S, N, L, C, scale):
+    """Exact-fp32 fused attention forward for L <= 64; S receives the probabilities (the unfused backward reads them)."""
+    call("mdm_attn_f32_small_fwd", ptr(qkv), ptr(o), ptr(S), N, L, C, float(scale), stream())
+
+
 def attn_bwd(dt, qkv, o, do, lse, delta, dqkv, N, L, C, scale):
     call("mdm_attn_bwd", dt, ptr(qkv), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dqkv), N, L, C, float(scale), stream())
 

@@ -403,6 +403,9 @@ class _AttnCore:
         self.S = n.alloc((N, L, L), n.tdtype)
         d = q.data.view(N, L, 3 * C)
         sc = 1.0 / math.sqrt(C)
+        if n.dt == F32 and ops.attn_f32_small_supported(L, C):     # one exact-fp32 launch; S = the probabilities, as below
+            ops.attn_f32_small_fwd(q.data, o.data, self.S, N, L, C, sc)
+            return
         ops.matmul(n.dt, 0, L, L, C, d, 3 * C, d[:, :, C:], 3 * C, self.S, L, batch=N, sA=L * 3 * C, sB=L * 3 * C, sD=L * L, alpha=sc)
         ops.softmax_fwd(n.dt, self.S, N * L, L)
         ops.matmul(n.dt, 1, L, C, L, self.S, L, d[:, :, 2 * C:], 3 * C, o.data, C, batch=N, sA=L * L, sB=L * 3 * C, sD=L * C)

@@ -373,6 +373,26 @@ def test_lin_split_stride2_and_tails(case):
     assert not torch.equal(outs["exact"], outs["split"]), "B_split was ignored: lin_split_kernel did not run"
 
 
+@pytest.mark.parametrize("N,L,C", [(100, 64, 256), (100, 16, 256), (5, 64, 64), (3, 48, 128), (2, 32, 64)])
+def test_attn_f32_small_forward(N, L, C):
+    """mdm_attn_f32_small_fwd: exact-fp32 fused attention for L <= 64 (the 8x8 / 4x4 attention blocks on the fp32 path) against fp64:
+    the output AND the probabilities it leaves for the unfused backward."""
+    from mdm import ops
+    g = torch.Generator().manual_seed(N + L + C)
+    qkv = torch.randn(N, L, 3 * C, generator=g)
+    q, k, v = qkv[..., :C].double(), qkv[..., C:2 * C].double(), qkv[..., 2 * C:].double()
+    sc = 1.0 / math.sqrt(C)
+    P = torch.softmax(q @ k.transpose(1, 2) * sc, dim=-1)
+    want = (P @ v).float()
+    assert ops.attn_f32_small_supported(L, C) and not ops.attn_f32_small_supported(80, C) and not ops.attn_f32_small_supported(L, 96)
+    o = torch.full((N, L, C), float("nan"), device=_dev())
+    S = torch.full((N, L, L), float("nan"), device=_dev())
+    ops.attn_f32_small_fwd(qkv.to(_dev()), o, S, N, L, C, sc)
+    torch.cuda.synchronize()
+    assert _relerr(S, P.float()) < 2e-6, _relerr(S, P.float())
+    assert _relerr(o, want) < 2e-6, _relerr(o, want)
+
+
 def test_conv_tap_split_with_epilogue():
     """Small-M 3x3 conv: reduction split over the filter taps (slabs + epilogue kernel), full epilogue."""
     from mdm import ops
