@@ -2832,10 +2832,14 @@ __global__ __launch_bounds__(512) void conv_halo_mixed_kernel(mdm_gemm_desc d, i
 // took 355 us of a 6.3 ms reverse step).  Rows beyond M read the zero page and are skipped by the epilogue.
 // Requires: KH = KW in {1, 3}, stride 1 (1x1) or 2, no upsample, C0 % 32 == C1 % 32 == 0, N % BN == 0.
 // ----------------------------------------------------------------------------
-template <int BN>
+template <int BN, int NS>
 __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
     constexpr int BM = 128, NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
-    constexpr int NS = 4, A_ST = BM * 128, B_ST = BN * 128, GA = BM / 64, GB = BN / 64, G = GA + GB;
+    // NS ring stages (slab s in stage s % NS): slab s multiplies, s+1 is split, s+2 .. s+NS-2 are in flight, s+NS-1 is issued into the
+    // stage slab s-1 left.  Four stages on both tiles (a deeper ring on the 64-channel tile -- six stages of 24 KB -- was measured
+    // slower: its layers pay the longer prologue, not the latency of the slabs in flight)
+    constexpr int A_ST = BM * 128, B_ST = BN * 128, GA = BM / 64, GB = BN / 64, G = GA + GB;
+    static_assert(NS >= 4, "lin_split: read / split / in flight / issue need four stages");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* const aring = lds;
     char* const bring = lds + NS * A_ST;
@@ -2878,7 +2882,7 @@ __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
     }
     int is_tap = 0, is_cs = 0, is_ty = 0, is_tx = 0;                // (tap, slab) of the next slab to issue: issue() is called in slab order
     auto issue = [&](int sl) {                                      // every wave issues G operations per slab, live or not
-        const int st = sl & (NS - 1), c = is_cs << 5;
+        const int st = sl % NS, c = is_cs << 5;
         const bool live = sl < NSL, s1 = c >= C0;
         const int poff = is_ty * IWs + is_tx;                       // source pixels between tap (0, 0) and this tap
 #pragma unroll
@@ -2892,7 +2896,7 @@ __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
         if (++is_cs == NCS) { is_cs = 0; ++is_tap; if (++is_tx == KW) { is_tx = 0; ++is_ty; } }
     };
     auto split_a = [&](int cs) {                                    // rows x chunk pairs of stage cs & 3: one item per thread
-        char* abuf = aring + (cs & (NS - 1)) * A_ST;
+        char* abuf = aring + (cs % NS) * A_ST;
         const int hr = t >> 2, pg = ((t & 3) ^ hr) & 7;
         f32x4* pa = reinterpret_cast<f32x4*>(abuf + hr * 128 + (pg << 4));
         f32x4* pb = reinterpret_cast<f32x4*>(abuf + hr * 128 + ((pg ^ 4) << 4));
@@ -2900,7 +2904,8 @@ __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
         split_bf16_pair(va, vb);
         *pa = va; *pb = vb;
     };
-    issue(0); issue(1); issue(2);
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u) issue(u);
     int a_off[MI], b_off[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -2917,17 +2922,17 @@ __global__ __launch_bounds__(512) void lin_split_kernel(mdm_gemm_desc d) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    wait_vmcnt<2 * G>();                                            // slab 0 has landed
+    wait_vmcnt<(NS - 2) * G>();                                     // slab 0 has landed
     __builtin_amdgcn_s_barrier();
     split_a(0);
     for (int s = 0; s < NSL; ++s) {
-        wait_vmcnt<G>();                                            // slabs <= s+1 have landed (this wave's pieces)
+        wait_vmcnt<(NS - 3) * G>();                                 // slabs <= s+1 have landed (this wave's pieces)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the split of slab s is written
         __builtin_amdgcn_s_barrier();                               // ... for every wave; slab s-1 is no longer read
-        issue(s + 3);
+        issue(s + NS - 1);
         if (s + 1 < NSL) split_a(s + 1);
-        const char* As = aring + (s & (NS - 1)) * A_ST;
-        const char* Bs = bring + (s & (NS - 1)) * B_ST;
+        const char* As = aring + (s % NS) * A_ST;
+        const char* Bs = bring + (s % NS) * B_ST;
         f32x4 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) { bh[j] = *reinterpret_cast<const f32x4*>(Bs + b_off[j]); bl[j] = *reinterpret_cast<const f32x4*>(Bs + (b_off[j] ^ 64)); }
@@ -3246,6 +3251,9 @@ static int halo_small_n_split(const mdm_gemm_desc& d) {
         return 0;
     return 256;
 }
+#ifndef MDM_LIN_SPLIT_NS64
+#define MDM_LIN_SPLIT_NS64 4        // ring stages of lin_split_kernel's 64-channel tile (six, 144 KB, measured 22.5 against 21.7 us per launch)
+#endif
 // lin_split_kernel: 0 = not eligible, else the channel tile (128, or 64 when 128 would leave the chip short of workgroups)
 static int lin_split_tile(const mdm_gemm_desc& d) {
     const bool k1 = d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad_t == 0 && d.pad_l == 0 && d.IH == d.OH && d.IW == d.OW;
@@ -3260,13 +3268,15 @@ static int lin_split_tile(const mdm_gemm_desc& d) {
 }
 template <int BN>
 static int launch_lin_split(const mdm_gemm_desc& d, hipStream_t s) {
-    constexpr int bytes = 4 * (128 * 128 + BN * 128);
+    constexpr int NS = BN == 64 ? MDM_LIN_SPLIT_NS64 : 4;
+    constexpr int bytes = NS * (128 * 128 + BN * 128);
+    static_assert(bytes <= 160 * 1024 && bytes >= 128 * BN * 4, "lin_split: ring / epilogue tile do not fit");
     static bool configured = false;
     if (!configured) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_split_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_split_kernel<BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((lin_split_kernel<BN>), dim3((unsigned)((int64_t)cdiv(d.M, 128) * (d.N / BN))), dim3(512), bytes, s, d);
+    hipLaunchKernelGGL((lin_split_kernel<BN, NS>), dim3((unsigned)((int64_t)cdiv(d.M, 128) * (d.N / BN))), dim3(512), bytes, s, d);
     return 0;
 }
 #ifndef MDM_NSB256
