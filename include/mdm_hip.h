@@ -172,6 +172,27 @@ int mdm_wgrad_group_launch(void* handle, void* stream);
 int mdm_wgrad_group_destroy(void* handle);
 
 /* ------------------------------------------------------------------------- *
+ * A CHAIN of small-map convolutions as one persistent launch.  The trunk of unet6 (4x4 and 8x8 maps: ResidualBlocks unet6.py:336-362,
+ * AttentionBlock projections :296-333, the level loop :478-506) is ~130 launches of 7-16 us per step at 32 images per GPU, most of
+ * each being launch boundary, prologue and drain.  A chain takes a run of consecutive mdm_gemm / mdm_gemm_pair calls whose tiles are
+ * 64 output pixels = whole images (the 64 x 32 halo tiles and 64 x 64 1x1 tiles mdm_gemm gives them) and runs them from ONE grid of
+ * resident workgroups: phase p's block for a set of images starts as soon as the blocks of phase p-1 that cover THOSE images have
+ * finished (per-image arrival counters, agent-scope release / acquire), with no grid-wide barrier and no dependence on where a
+ * workgroup is placed.  The arithmetic is that of the separate launches, bit for bit.
+ *   descs_host: the descriptors of all phases back to back; roles[p] in {1, 2} = how many of them phase p takes (2 = the pair
+ *   mdm_gemm_pair would fuse: a 3x3 convolution + a 1x1 projection).  Every phase must pass mdm_chain_accepts.  dev_buf / need_bytes_out
+ *   as in mdm_wgrad_group_create (size query with dev_buf = NULL); the buffer holds the descriptor copies, the phase table and the
+ *   counters, which mdm_chain_launch clears (one small launch) before the persistent one.  mdm_chain_status: 0 unless a bounded wait
+ *   inside some launch timed out (the launch then still ended, with wrong results).
+ * ------------------------------------------------------------------------- */
+int mdm_chain_accepts(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b_host /* NULL: a single convolution */);
+int mdm_chain_create(const mdm_gemm_desc* descs_host, const int* roles, int n_phases, void* dev_buf, int64_t dev_bytes,
+                     int64_t* need_bytes_out, void** handle_out);
+int mdm_chain_launch(void* handle, void* stream);
+int mdm_chain_status(void* handle, unsigned* err_out);
+int mdm_chain_destroy(void* handle);
+
+/* ------------------------------------------------------------------------- *
  * GroupNorm(32, eps) [+ SiLU]  (unet6.py:291-293, 358, 360, 330, 505)
  * x = concat(src0[C0], src1[C1]) along channels, NHWC, P = H*W pixels per image.
  * stats: [N][G][2] fp32 (mean, rstd).  One kernel per call, every sum in a fixed order (no float atomics); `ws` is
@@ -188,6 +209,10 @@ int mdm_groupnorm_bwd(int dtype, const void* src0, int C0, const void* src1, int
                       int N, int P, int G, const float* gamma, const float* beta, int silu,
                       const void* dy, const float* stats, void* dst0, int acc0, void* dst1, int acc1,
                       float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* floats the three backward entry points write into `ws` for an [N][P][C] problem of this dtype (0: `ws` may be NULL).  Replaces the
+ * sizes quoted in prose above: the entry points cannot check a size they are not given. */
+int64_t mdm_groupnorm_bwd_ws_floats(int dtype, int N, int C);
 
 /* Same, and the column sums of the dx it writes (dx = the complete gradient of a conv output: acc0 == 0, one
  * source): sum_img[n*sum_ld + c] = sum_p dx (the time-embedding gradient, unet6.py:359) and

@@ -3022,6 +3022,109 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(mdm_gemm_desc a, mdm_gem
     else conv_lin2_body<LBM, LBN, LNS, LWR, LWC, 1, true, false>(b, lds, (int)blockIdx.x - na, (int)gridDim.x - na, 0);
 }
 
+
+// ----------------------------------------------------------------------------
+// CHAIN: consecutive convolutions of the U-Net's small-map trunk (4x4 / 8x8: unet6.py:336-362, 296-333, 478-506) as ONE persistent
+// launch (mdm_chain_*).  At 32 images per GPU each of those layers is a 9-16 us launch for 1-4 us of loop (DESIGN findings 23, 26): the
+// fixed parts of a launch -- boundary, prologue, drain -- are what the trunk's time is made of.  Here a grid of resident workgroups (one
+// per CU) walks the layers ("phases") in order; a phase is one mdm_gemm or one mdm_gemm_pair, its virtual blocks are dealt out with
+// stride gridDim.x and run the SAME device bodies (conv_halo_body / conv_lin2_body) as the per-layer launches -- the results are
+// bit-identical to them.
+//   Dependencies.  Every tile of these phases is 64 output pixels = whole images (one 8x8 image or four 4x4 images) and a
+//   convolution reads only the pixels of its own images, so a block of phase p needs exactly the blocks of phase p-1 that cover ITS
+//   images -- not a grid-wide barrier.  cnt[p][image] counts the finished blocks of phase p that cover that image; a block of phase p
+//   waits until cnt[p-1][img] == target[p-1] for each of its images.  Because the wait is on ALL blocks of p-1 for those images and
+//   each of them had waited for all of p-2's, everything any earlier phase wrote for these images is complete too (residuals, skip
+//   tensors, GroupNorm statistics), and a later phase cannot overwrite what an earlier one still reads.
+//   Visibility (cdna_hip_programming.md Guideline 16): producer = every wave drains its stores (vmcnt(0)), workgroup barrier, one
+//   lane releases at agent scope, then the counter adds; consumer = one wave polls (relaxed, agent scope), ONE agent-scope acquire,
+//   vmcnt(0), workgroup barrier, then plain / LDS-DMA loads.  Nothing depends on which XCD a workgroup lands on.
+//   Progress.  Every workgroup walks (phase, block) in the same global order and waits only on earlier phases; with all gridDim.x
+//   workgroups resident (grid <= CUs: one workgroup per CU by its LDS request) the earliest unfinished block is never blocked.  The
+//   spin is bounded all the same: on a timeout the error word is set and the launch ends (with wrong results) instead of hanging.
+// ----------------------------------------------------------------------------
+struct ChainPhase {
+    int kind[2];            // role 0 / role 1 (mdm_gemm_pair): 0 = halo 64x32 (2 pieces per wave), 1 = halo 64x32 (3 pieces), 2 = lin2 64x64, -1 = none
+    int desc[2];
+    int nblk[2];
+    int tiles_n[2];         // channel tiles per 64-pixel row tile
+    int img_sh;             // log2(images per row tile): 0 on 8x8 maps, 2 on 4x4
+    unsigned target;        // finished blocks per image that complete this phase
+    unsigned prev_target;   // ... the phase in front of it (0: nothing to wait for)
+    int pad;
+};
+#ifdef MDM_STAMP
+#define MDM_CHAIN_STAMP_BASE 16384          // records [16384, 32768) of g_stamp_buf: one per (phase, virtual block)
+#endif
+
+__global__ __launch_bounds__(512) void chain_zero_kernel(unsigned* cnt, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt[i] = 0u;
+}
+
+__global__ __launch_bounds__(512) void chain_kernel(const mdm_gemm_desc* __restrict__ descs, const ChainPhase* __restrict__ phases,
+                                                    const int n_ph, unsigned* cnt, const int n_img, unsigned* err) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x;
+    for (int p = 0; p < n_ph; ++p) {
+        const ChainPhase P = phases[p];
+        const int total = P.nblk[0] + P.nblk[1];
+        unsigned* const mine = cnt + (int64_t)p * n_img;
+        const unsigned* const prev = cnt + (int64_t)(p - 1) * n_img;
+        for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+            const int role = vb >= P.nblk[0] ? 1 : 0;
+            const int bx = role ? vb - P.nblk[0] : vb, gx = P.nblk[role];
+            const int rt = udiv_small(xcd_remap(bx, gx), P.tiles_n[role]);     // the row tile the body will compute (same arithmetic)
+            const int nimg = 1 << P.img_sh, img0 = rt << P.img_sh;
+            MDM_T(const unsigned long long t_w0 = stamp_now();)
+            if (P.prev_target != 0u) {
+                if (t < 64) {                                   // wave 0: lane i polls the counter of image img0 + i
+                    bool ok = true;
+                    if (t < nimg) {
+                        const unsigned* c = prev + img0 + t;
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.prev_target) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1u << 20)) { ok = false; break; }
+                        }
+                    }
+                    if (!ok) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+            }
+            MDM_T(const unsigned long long t_w1 = stamp_now();)
+            {
+                const mdm_gemm_desc d = descs[P.desc[role]];
+                const int kind = P.kind[role];
+                if (kind == 0) conv_halo_body<64, 2, 32, 3, 3>(d, lds, bx, gx);
+                else if (kind == 1) conv_halo_body<64, 3, 32, 3, 3>(d, lds, bx, gx);
+                else conv_lin2_body<64, 64, 4, 4, 2, 1, true, false>(d, lds, bx, gx, 0);
+            }
+            MDM_T(const unsigned long long t_b1 = stamp_now();)
+            // publish: every wave's stores have been acknowledged, then one release for the workgroup, then the arrivals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                    // (also: the next block may refill the LDS)
+            if (t < 64) {
+                if (t == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (t < nimg) __hip_atomic_fetch_add(mine + img0 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#ifdef MDM_STAMP
+            if (t == 0) {
+                const unsigned rec = MDM_CHAIN_STAMP_BASE + (unsigned)p * 512u + (unsigned)vb;
+                if (vb < 512 && rec < MDM_STAMP_RECS) {
+                    unsigned long long* r = g_stamp_buf + (size_t)rec * 32;
+                    r[0] = t_w0; r[1] = t_w1; r[2] = t_b1; r[3] = stamp_now(); r[4] = stamp_hw_id(); r[5] = (unsigned long long)blockIdx.x; r[6] = 1;
+                }
+            }
+#endif
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // host launch
 // ----------------------------------------------------------------------------
@@ -3605,6 +3708,43 @@ struct WgradGroup {
 struct GroupItem { int desc, item, tiles_x, big, cost; };
 struct TapsTile { int desc, tile, slabs; };
 
+
+// ---- chains of small-map convolutions in one persistent launch (chain_kernel) ------------------------------------
+struct Chain {
+    const mdm_gemm_desc* descs_dev = nullptr;
+    const ChainPhase* phases_dev = nullptr;
+    unsigned* cnt_dev = nullptr;            // [n_ph][n_img] arrival counters + 4 words (error, spare)
+    int n_ph = 0, n_img = 0, grid = 0, lds_bytes = 0;
+};
+// 0 = halo 64x32 with 2 pieces per wave, 1 = with 3, 2 = lin2 64x64, -1 = not a chain link
+static int chain_kind(const mdm_gemm_desc* dh, Resolved& r, int* lds_bytes) {
+    if (resolve(dh, false, r)) return -1;
+    const mdm_gemm_desc& d = r.d;
+    if (check_fused_gn(d)) return -1;
+    const unsigned z = (unsigned)(r.zouter * d.splitk);
+    if (z != 1 || r.tap_split || d.splitk > 1 || !d.conv || d.layout != 0 || d.dtype != MDM_BF16) return -1;
+    const int P = d.OH * d.OW;
+    if (!(P == 16 || P == 64) || d.M % 64 != 0 || d.M % P != 0) return -1;
+    const ConvVar cv = conv_variant(d, r, z);
+    if (cv == CV_H64_2_32 || cv == CV_H64_3_32) {
+        const int NPA = halo_pieces(64, d.OH, d.OW);
+        int bytes = 2 * NPA * 1024 + 3 * 3 * 32 * 128 + 1024;                       // as launch_halo<64, NPW, 3, 32>
+        if (bytes < 64 * 32 * 4) bytes = 64 * 32 * 4;
+        if (d.gnb_x && bytes < 16384 + 65536 + 4096 + 512) bytes = 16384 + 65536 + 4096 + 512;
+        if (d.gnf_out && bytes < 16384 + 16384 + 4096) bytes = 16384 + 16384 + 4096;
+        if (NPA > 8 * (cv == CV_H64_2_32 ? 2 : 3)) return -1;
+        *lds_bytes = bytes;
+        return cv == CV_H64_2_32 ? 0 : 1;
+    }
+    if (cv == CV_L64 && r.tiles < (1ll << 20)) {
+        int bytes = 4 * (64 + 64) * 64 * 2;                                        // as launch_lin2<64, 64, 4, 4, 2>
+        if (d.gnb_x && bytes < 16384 + 65536 + 4096 + 512) bytes = 16384 + 65536 + 4096 + 512;
+        *lds_bytes = bytes;
+        return 2;
+    }
+    return -1;
+}
+
 }  // namespace mdm
 using namespace mdm;
 
@@ -3663,6 +3803,106 @@ extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b
     if (rc) return rc;
     return launch_status("gemm pair launch");
 }
+
+// ---- mdm_chain_*: see chain_kernel ----------------------------------------------------------------------------------
+extern "C" int mdm_chain_accepts(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b_host) {
+    if (!a_host) return 0;
+    Resolved ra, rb;
+    int la = 0, lb = 0;
+    const int ka = chain_kind(a_host, ra, &la);
+    if (ka < 0) return 0;
+    if (!b_host) return 1;
+    const int kb = chain_kind(b_host, rb, &lb);
+    // a pair = a halo convolution + a 1x1 projection without a fused GroupNorm epilogue (what mdm_gemm_pair fuses), same batch and map
+    return (ka <= 1 && kb == 2 && !rb.d.gnb_x && !rb.d.gnf_out && ra.d.M == rb.d.M && ra.d.OH == rb.d.OH && ra.d.OW == rb.d.OW) ? 1 : 0;
+}
+extern "C" int mdm_chain_create(const mdm_gemm_desc* descs_host, const int* roles, int n_phases, void* dev_buf, int64_t dev_bytes,
+                                int64_t* need_bytes_out, void** handle_out) {
+    MDM_REQUIRE(descs_host && roles && n_phases > 0 && need_bytes_out && handle_out, "chain_create: bad arguments");
+    *handle_out = nullptr;
+    static const int n_cu = [] {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
+        return pr.multiProcessorCount;
+    }();
+    std::vector<mdm_gemm_desc> ds;
+    std::vector<ChainPhase> ph((size_t)n_phases);
+    int n_img = 0, lds_max = 0, max_blocks = 0, di = 0;
+    unsigned prev_target = 0;
+    for (int p = 0; p < n_phases; ++p) {
+        MDM_REQUIRE(roles[p] == 1 || roles[p] == 2, "chain_create: phase %d has %d descriptors (1 or 2)", p, roles[p]);
+        ChainPhase& P = ph[(size_t)p];
+        P.kind[1] = -1; P.desc[1] = 0; P.nblk[1] = 0; P.tiles_n[1] = 1; P.pad = 0;
+        MDM_REQUIRE(mdm_chain_accepts(descs_host + di, roles[p] == 2 ? descs_host + di + 1 : nullptr) == 1,
+                    "chain_create: phase %d is not a chain link (mdm_chain_accepts)", p);
+        unsigned target = 0;
+        for (int q = 0; q < roles[p]; ++q) {
+            Resolved r;
+            int lb = 0;
+            const int k = chain_kind(descs_host + di + q, r, &lb);
+            const mdm_gemm_desc& d = r.d;
+            const int Pix = d.OH * d.OW, imgs = d.M / Pix, bn = k == 2 ? 64 : 32;
+            MDM_REQUIRE(n_img == 0 || n_img == imgs, "chain_create: phase %d works on %d images, the chain on %d", p, imgs, n_img);
+            n_img = imgs;
+            P.kind[q] = k; P.desc[q] = (int)ds.size(); P.tiles_n[q] = cdiv(d.N, bn); P.nblk[q] = (d.M / 64) * P.tiles_n[q];
+            P.img_sh = Pix == 64 ? 0 : 2;
+            target += (unsigned)P.tiles_n[q];
+            lds_max = lb > lds_max ? lb : lds_max;
+            ds.push_back(d);
+        }
+        P.target = target; P.prev_target = prev_target;
+        prev_target = target;
+        max_blocks = std::max(max_blocks, P.nblk[0] + P.nblk[1]);
+        di += roles[p];
+    }
+    MDM_REQUIRE(lds_max <= 160 * 1024, "chain_create: %d bytes of LDS", lds_max);
+    auto pad256 = [](int64_t v) { return (v + 255) / 256 * 256; };
+    const int64_t desc_bytes = pad256((int64_t)ds.size() * (int64_t)sizeof(mdm_gemm_desc)), ph_bytes = pad256((int64_t)n_phases * (int64_t)sizeof(ChainPhase));
+    const int64_t cnt_bytes = pad256(((int64_t)n_phases * n_img + 4) * 4);
+    *need_bytes_out = desc_bytes + ph_bytes + cnt_bytes;
+    if (!dev_buf || dev_bytes < *need_bytes_out) return 0;          // size query
+    char* base = reinterpret_cast<char*>(dev_buf);
+    hipError_t e = hipMemcpy(base, ds.data(), ds.size() * sizeof(mdm_gemm_desc), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(base + desc_bytes, ph.data(), ph.size() * sizeof(ChainPhase), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(base + desc_bytes + ph_bytes, 0, (size_t)cnt_bytes);
+    if (e != hipSuccess) return hip_fail(e, "chain_create: hipMemcpy");
+    Chain* c = new Chain();
+    c->descs_dev = reinterpret_cast<const mdm_gemm_desc*>(base);
+    c->phases_dev = reinterpret_cast<const ChainPhase*>(base + desc_bytes);
+    c->cnt_dev = reinterpret_cast<unsigned*>(base + desc_bytes + ph_bytes);
+    c->n_ph = n_phases; c->n_img = n_img;
+    c->grid = std::min(n_cu, max_blocks);              // every workgroup resident: one per CU (a workgroup asks for > 80 KiB of LDS or the grid is <= CUs anyway)
+    c->lds_bytes = std::max(lds_max, 81 * 1024);       // > half of a CU's LDS: never two of these workgroups on one CU
+    *handle_out = c;
+    return 0;
+}
+extern "C" int mdm_chain_launch(void* handle, void* stream) {
+    MDM_REQUIRE(handle, "chain_launch: null handle");
+    const Chain* c = reinterpret_cast<const Chain*>(handle);
+    hipStream_t s = pick_stream(stream);
+    static int configured = 0;
+    if (configured < c->lds_bytes) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes));
+        configured = c->lds_bytes;
+    }
+    const int n_cnt = c->n_ph * c->n_img;
+    hipLaunchKernelGGL(chain_zero_kernel, dim3((unsigned)cdiv(n_cnt, 512)), dim3(512), 0, s, c->cnt_dev, n_cnt);
+    hipLaunchKernelGGL(chain_kernel, dim3((unsigned)c->grid), dim3(512), (size_t)c->lds_bytes, s, c->descs_dev, c->phases_dev, c->n_ph, c->cnt_dev,
+                       c->n_img, c->cnt_dev + n_cnt);
+    return launch_status("chain");
+}
+// the error word of the chain's last launches (0 = every wait was satisfied); synchronises with the device
+extern "C" int mdm_chain_status(void* handle, unsigned* err_out) {
+    MDM_REQUIRE(handle && err_out, "chain_status: bad arguments");
+    const Chain* c = reinterpret_cast<const Chain*>(handle);
+    MDM_CHECK_HIP(hipMemcpy(err_out, c->cnt_dev + c->n_ph * c->n_img, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int mdm_chain_destroy(void* handle) {
+    delete reinterpret_cast<Chain*>(handle);
+    return 0;
+}
+
 extern "C" int mdm_gemm_can_fuse_gn_bwd(const mdm_gemm_desc* desc_host, int G) {
     if (!desc_host || G <= 0) return 0;
     mdm_gemm_desc d = *desc_host;

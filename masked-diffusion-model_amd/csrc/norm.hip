@@ -909,6 +909,12 @@ extern "C" int mdm_groupnorm_fwd(int dtype, const void* src0, int C0, const void
     return launch_status("groupnorm_fwd");
 }
 
+// floats of `ws` the backward entry points write for this problem (0: none needed).  The C ABI carries no buffer sizes, so a caller
+// sizes its workspace with this query instead of with a constant from the header's prose.
+extern "C" int64_t mdm_groupnorm_bwd_ws_floats(int dtype, int N, int C) {
+    return dtype == MDM_F32 ? (int64_t)3 * N * C : 0;
+}
+
 extern "C" int mdm_groupnorm_bwd_add(int dtype, const void* src0, int C0, const void* src1, int C1, int N, int P, int G,
                                      const float* gamma, const float* beta, int silu, const void* dy, const float* stats,
                                      void* dst0, const void* add0, void* dst1, const void* add1, float* dgamma, float* dbeta,

@@ -48,12 +48,18 @@ _PROTOS = {
     "mdm_wgrad_group_create": ([C.POINTER(GemmDesc), i32, vp, i64, C.POINTER(i64), C.POINTER(vp)], i32),
     "mdm_wgrad_group_launch": ([vp, vp], i32),
     "mdm_wgrad_group_destroy": ([vp], i32),
+    "mdm_chain_accepts": ([C.POINTER(GemmDesc), C.POINTER(GemmDesc)], i32),
+    "mdm_chain_create": ([C.POINTER(GemmDesc), C.POINTER(i32), i32, vp, i64, C.POINTER(i64), C.POINTER(vp)], i32),
+    "mdm_chain_launch": ([vp, vp], i32),
+    "mdm_chain_status": ([vp, C.POINTER(C.c_uint32)], i32),
+    "mdm_chain_destroy": ([vp], i32),
     "mdm_gemm_plan": ([C.POINTER(GemmDesc), C.POINTER(i32), C.POINTER(i64)], i32),
     "mdm_gemm_can_fuse_gn_bwd": ([C.POINTER(GemmDesc), i32], i32),
     "mdm_gemm_can_fuse_gn_fwd": ([C.POINTER(GemmDesc), i32], i32),
     "mdm_groupnorm_fwd": ([i32, vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp], i32),
     "mdm_groupnorm_bwd_sums": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp], i32),
+    "mdm_groupnorm_bwd_ws_floats": ([i32, i32, i32], i64),
     "mdm_groupnorm_bwd_add": ([i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp], i32),
     "mdm_attn_supported": ([i32, i32, i32], i32),
     "mdm_attn_fwd": ([i32, vp, vp, vp, i32, i32, i32, f32, vp], i32),
@@ -347,6 +353,90 @@ class WgradGroup:
                 load().mdm_wgrad_group_destroy(self.handle)
         except Exception:
             pass
+
+
+class Chain:
+    """Handle of mdm_chain_*: consecutive small-map convolutions (each an `mdm_gemm` or an `mdm_gemm_pair`) that run as ONE
+    persistent launch with per-image hand-offs between the layers instead of launch boundaries (csrc/gemm.hip chain_kernel).
+    `phases`: list of tuples of 1 or 2 GemmDesc.  The descriptors are copied into a device table at creation."""
+
+    def __init__(self, phases, device):
+        lib = load()
+        flat = [d for ph in phases for d in ph]
+        arr = (GemmDesc * len(flat))()
+        for i, d in enumerate(flat):
+            C.memmove(C.byref(arr, i * C.sizeof(GemmDesc)), C.byref(d), C.sizeof(GemmDesc))
+        roles = (i32 * len(phases))(*[len(ph) for ph in phases])
+        need, h = i64(), vp()
+        check(lib.mdm_chain_create(arr, roles, len(phases), None, 0, C.byref(need), C.byref(h)), "mdm_chain_create")
+        self.table = torch.empty(need.value, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        check(lib.mdm_chain_create(arr, roles, len(phases), self.table.data_ptr(), need.value, C.byref(need), C.byref(h)), "mdm_chain_create")
+        assert h.value, "chain was not built"
+        self.handle, self.n, self.keep = h, len(phases), phases
+
+    def status(self):
+        """0 if every in-kernel wait of the launches so far was satisfied (synchronises)."""
+        e = C.c_uint32()
+        check(load().mdm_chain_status(self.handle, C.byref(e)), "mdm_chain_status")
+        return e.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().mdm_chain_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def chain_accepts(da, db=None):
+    return bool(load().mdm_chain_accepts(C.byref(da), C.byref(db) if db is not None else None))
+
+
+def chained(rec, device, min_len=2):
+    """A copy of Recording `rec` in which every maximal run of >= `min_len` consecutive chainable launches (mdm_gemm /
+    mdm_gemm_pair calls that mdm_chain_accepts) is ONE mdm_chain_launch.  Same kernels' bodies, same results, fewer launches."""
+    lib = load()
+    out = Recording()
+    out.keep = list(rec.keep)
+    out.chains = []
+    run = []            # [(index, descs)]
+
+    def flush():
+        nonlocal run
+        if len(run) >= min_len:
+            ch = Chain([d for _, d in run], device)
+            out.chains.append(ch)
+            out.keep.append(ch)
+            fl = [rec.flops[i] for i, _ in run if i in rec.flops]
+            if fl:
+                out.flops[len(out.calls)] = (sum(f for f, _ in fl), fl[0][1])
+            out.calls.append(("mdm_chain_launch", lib.mdm_chain_launch, (ch.handle,)))
+        else:
+            for i, _ in run:
+                if i in rec.flops:
+                    out.flops[len(out.calls)] = rec.flops[i]
+                out.calls.append(rec.calls[i])
+        run = []
+    for i, (name, fn, args) in enumerate(rec.calls):
+        descs = None
+        if name == "mdm_gemm":
+            d = args[0]._obj
+            if chain_accepts(d):
+                descs = (d,)
+        elif name == "mdm_gemm_pair":
+            da, db = args[0]._obj, args[1]._obj
+            if chain_accepts(da, db):
+                descs = (da, db)
+        if descs is None:
+            flush()
+            if i in rec.flops:
+                out.flops[len(out.calls)] = rec.flops[i]
+            out.calls.append(rec.calls[i])
+        else:
+            run.append((i, descs))
+    flush()
+    return out
 
 
 def wgrad_group_accepts(**kw):

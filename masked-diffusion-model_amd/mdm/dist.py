@@ -27,8 +27,13 @@ def init_from_env(backend=None, single=False):
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not single:
         return
     if single:
-        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
             os.environ.setdefault(k, v)
+        if "MASTER_PORT" not in os.environ:        # a free port: two rehearsals on one host must not meet on a fixed one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl" and os.environ.get("MDM_FORCE_DEVICE") is None:

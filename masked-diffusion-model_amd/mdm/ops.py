@@ -221,6 +221,9 @@ def groupnorm_bwd(dt, src0, C0, src1, C1, N, P, gamma, beta, silu, dy, stats, ds
                   dgamma, dbeta, ws, G=32, sum_img=None, sum_ld=0, sum_all=None, add0=None, add1=None):
     """dst = (acc ? dst : add or 0) + dx.  add0 / add1: tensors laid out like dst0 / dst1 that are added without being
     modified (the gradient arriving over a residual branch)."""
+    need = _lib.load().mdm_groupnorm_bwd_ws_floats(dt, N, C0 + C1)
+    if need and (ws is None or ws.numel() < need):
+        raise ValueError(f"groupnorm_bwd: workspace of {0 if ws is None else ws.numel()} floats, {need} needed")
     a0 = dst0 if acc0 else add0
     a0b = add0 if acc0 else None            # accumulate AND a pending addend: both are added
     assert not (acc1 and add1 is not None), "groupnorm_bwd: the second source takes one addend"

@@ -55,6 +55,13 @@ class TrainStep:
         self.model, self.S, self.args, self.opt, self.ema = model, scheduler, args, optimizer, ema
         self.mean_shift = mean_shift
         self.comm = comm                      # mdm.dist.GradComm or None
+        if comm is not None and getattr(comm, "exchange", False) and len(getattr(model, "wgrad_groups", ())) <= 1 \
+                and model.store.size * 4 > 2 * comm.bucket_bytes:
+            # a model built BEFORE the process group was initialised planned ONE weight-gradient group (= one gradient bucket):
+            # correct, but the whole exchange is then exposed behind the backward
+            import warnings
+            warnings.warn("TrainStep: data-parallel run over a model with a single weight-gradient group -- build the UNet after "
+                          "mdm.dist.init_from_env() (or pass wgrad_group_bytes=32 << 20) so that gradient buckets can overlap the backward")
         self.max_norm = max_norm
         self.grad_accum = int(grad_accum)
         if self.grad_accum < 1:
@@ -109,9 +116,14 @@ class TrainStep:
         N, C, H, W = m.N, m.cin, m.H, m.W
         dev = m.device
         self.x0.copy_(x0.to(torch.float32))
-        timeindex = torch.randint(low=0, high=len(used), size=(N,))                       # ms:109
-        t = torch.index_select(torch.tensor(used), 0, timeindex)
-        t = t.to(torch.float32) if self.mean_shift else t                                 # ms:110 / base:115
+        # Data-parallel replay (`Scheduler.replay_rows = (lo, hi, n)`): the reference seeds every rank alike, so each rank draws the
+        # host numbers of the WHOLE n-sample batch and keeps its rows -- the ranks together see exactly what one process with n
+        # samples draws (tests/test_ema_dp_gpu.py compares the two).
+        nh, rows = S._host_rows(N)
+        timeindex = torch.randint(low=0, high=len(used), size=(nh,))                      # ms:109
+        t_all = torch.index_select(torch.tensor(used), 0, timeindex)
+        t_all = t_all.to(torch.float32) if self.mean_shift else t_all                     # ms:110 / base:115
+        timeindex, t = timeindex[rows], t_all[rows]
         amount = S.get_black_area_num_pixels_time(t.to(dev))                              # ms:112
         weights_on = bool(getattr(a, "loss_weight_use", False))
         if weights_on:
@@ -121,19 +133,21 @@ class TrainStep:
         if a.select_degrade_pixel == "indexing":
             if amount.dtype.is_floating_point:
                 raise TypeError("indexing needs integer pixel counts (D7)")
-            mk = torch.ones(N, H * W)
-            for i, num in enumerate(amount.cpu()):
+            amount_all = S.get_black_area_num_pixels_time(t_all.to(dev)) if nh != N else amount
+            mk = torch.ones(nh, H * W)
+            for i, num in enumerate(amount_all.cpu()):
                 mk[i, torch.randperm(H * W)[:num]] = 0.0                                  # scheduler.py:281-282
-            mask_in = mk.reshape(N, 1, H, W).expand(N, C, H, W).contiguous().to(dev)
+            mask_in = mk[rows].reshape(N, 1, H, W).expand(N, C, H, W).contiguous().to(dev)
         else:
             Cm = S._check_degrade_args(self.x0)
             self.amount.copy_(amount)
-            u = torch.empty(N, Cm * H * W).uniform_(0.0, 1.0).to(dev)                     # scheduler.py:288/294
+            u = torch.empty(nh, Cm * H * W).uniform_(0.0, 1.0)[rows].contiguous().to(dev)  # scheduler.py:288/294
         kind = self._kind()
         z = None
         if kind != 0:
             self.ratio.copy_(torch.index_select(S.ratio_dev, 0, (t.int() - 1).to(dev)))
-            z = S._shift_draws(N, C, H, W, self.ratio.cpu()).to(dev).contiguous()
+            ratio_all = torch.index_select(S.ratio_list, 0, (t_all.int() - 1).long()) if nh != N else self.ratio.cpu()
+            z = S._shift_draws(nh, C, H, W, ratio_all)[rows].to(dev).contiguous()
         m.t_in.copy_(t.to(torch.float32))
         self.loss.zero_()                   # (the device path clears it in its first launch, mdm_draw_timesteps)
         self._emit_forward_loss(u, z, mask_in, Cm, weights_on)

@@ -595,7 +595,10 @@ class UNet:
         assert precision in ("f32_split", "f32", "model"), precision
         if precision == "model" or (precision == "f32" and self.dt == F32 and not self.split_products) or \
                 (precision == "f32_split" and self.dt == F32 and self.split_products):
-            return self.with_batch(N)
+            net = self.with_batch(N)
+            if net.split_products:
+                net.store.emit_split_shadow()
+            return net
         products = "split" if precision == "f32_split" else "exact"
         plans = self.__dict__.setdefault("_sampling_plans", {})
         key = (N, precision)
@@ -614,6 +617,11 @@ class UNet:
             assert net.store.size == self.store.size
             net.store.P.copy_(self.store.P)
             net.store.sync_shadow()
+        elif net.split_products:
+            # A shared fp32 store: the hi / lo filter shadow is refreshed by the optimizer tail only if it existed when that tail was
+            # recorded (a TrainStep graph captured before the first sampling_plan call has no such launch).  One cheap launch here
+            # makes "THIS model's current weights" true whatever was captured when.
+            net.store.emit_split_shadow()
         net.training = self.training
         return net
 

@@ -527,3 +527,69 @@ def test_sampler_shards_sample_num_over_two_ranks(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert "SHARD_OK" in outs[0]
+
+
+# ------------------------------------------------------------------------------------------- free-running T = 1000 on a TRAINED net
+def _trained_tiny():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "trained_tiny.npz"))
+    return {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}, float(z["yardstick_fp32_vs_fp64"])
+
+
+_TRAINED_ORACLE = {}
+
+
+@pytest.mark.parametrize("dep,mode", [("independent", "base_sampling"), ("dependent_prev", "base_momentum"), ("dependent_prev", "base_sampling"),
+                                      ("independent", "base_momentum")])
+@pytest.mark.parametrize("prec", ["f32", "f32_split", "bf16"])
+def test_sampler_1000_steps_free_running_on_trained_weights(dep, mode, prec):
+    """north_star's literal claim -- "sampler output within 1e-3 rel-L2 of the CPU reference" -- end to end: ALL 1000 reverse steps of
+    cfg2's schedule FREE-RUNNING (no teacher forcing) against the oracle (reference sampler.py:137-258), on TINY weights that the
+    oracle's own train step has trained on structured synthetic images (tests/golden/make_trained_tiny.py, trained_tiny.npz).  On
+    untrained random weights the same run measures conditioning, not parity (the oracle is 0.75 from its own fp64 run).  With the
+    trained net three of the four (mask dependency, momentum) combinations are well conditioned -- oracle fp32 vs fp64: 3e-6
+    (independent / base_sampling), 1.4e-5 (dependent_prev / base_momentum), 5e-7 (dependent_prev / base_sampling) -- and are ASSERTED
+    at 1e-3 for exact fp32 and for the sampler of record (fp32 storage, split products); bf16 storage is reported.  The fourth,
+    independent / base_momentum -- the bench's mode -- stays explosive even on the trained net (x_t += D_{t-1} - D_t with two
+    INDEPENDENT masks integrates the difference of two masked images at every step: |x0| ~ 1e3, oracle fp32 vs fp64 0.5-1.0): it is
+    recorded, not asserted, and covered step by step by the teacher-forced test above."""
+    import mdm
+    from oracle.sampler_ref import SamplerRef
+    from oracle.scheduler_ref import SchedulerRef
+    from oracle.unet_ref import UNetRef
+    params, _ = _trained_tiny()
+    n, hw, T = 4, 16, 1000
+    a = base_args(data_size=hw, ddpm_schedule="linear", ddpm_num_steps=T, shift_type="noise_with_perturbation",
+                  sampling_mask_dependency=dep, momentum_adaptive=mode, sample_num=n, sample_latent_shape="uniform", sample_history=False)
+    if (dep, mode) not in _TRAINED_ORACLE:
+        rs = SchedulerRef(a)
+        rs.update_ddpm_num_steps(T)
+        ts = rs.get_timesteps_epoch(0, 1)
+        seed_all(4252)
+        with torch.no_grad():
+            want, _ = SamplerRef(None, a, rs, [None] * 3).sample(UNetRef(TINY, params), ts)
+        m64 = UNetRef(TINY, params, dtype=torch.float64)
+        rs64 = SchedulerRef(a)
+        rs64.update_ddpm_num_steps(T)
+        seed_all(4252)
+        with torch.no_grad():
+            w64, _ = SamplerRef(None, a, rs64, [None] * 3).sample(lambda x, t: SimpleNamespace(sample=m64(x, t).sample.float()), ts)
+        _TRAINED_ORACLE[(dep, mode)] = (want, _rel(want, w64))
+    want, yard = _TRAINED_ORACLE[(dep, mode)]
+    dt, products = (mdm.BF16, "exact") if prec == "bf16" else (mdm.F32, "split" if prec == "f32_split" else "exact")
+    model = mdm.UNet(TINY, N=n, H=hw, W=hw, dtype=dt, params=params, f32_products=products).eval()
+    s = mdm.Scheduler(a)
+    s.update_ddpm_num_steps(T)
+    ts = s.get_timesteps_epoch(0, 1)
+    assert len(ts) == T
+    seed_all(4252)
+    x0, hist = mdm.Sampler(None, a, s, [None] * 3).sample(model, ts)
+    torch.cuda.synchronize()
+    assert hist == [] and bool(torch.isfinite(x0).all())
+    rel = _rel(x0, want)
+    _note("sampler_1000_free_running_trained", dict(precision=prec, dep=dep, mode=mode, rel_l2=rel, oracle_fp32_vs_fp64=yard,
+                                                    max_abs_x0=float(want.abs().max())))
+    if (dep, mode) == ("independent", "base_momentum"):
+        return                                  # explosive by construction (docstring): recorded only
+    assert yard < 1e-4, yard                    # the configuration is well conditioned: the claim is testable
+    if prec != "bf16":
+        assert rel < 1e-3, (rel, yard)
