@@ -1219,7 +1219,34 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 // of one pixel: residual, accumulate and the store are 16-byte accesses, 256 B contiguous per 16 lanes.
 // Rounding happens once, after every fp32 term is in -- same arithmetic as epilogue4.
 // ----------------------------------------------------------------------------
-template <int BM, int BN, int NW, int MI, int NI, typename T = bf16_t>
+// Tile stores of a convolution that runs as a phase of a CHAIN (chain_kernel instantiates the bodies with WT): WRITE-THROUGH (sc1), so
+// that the consumer workgroup of the next phase finds the bytes in memory once this workgroup's waves have drained their stores --
+// no agent-scope release (an L2 write-back: 6-8 us per hand-off with plain stores, MI355X_MICROARCH.md "publish-large").  hipcc does
+// not count an asm store (the chain drains with an explicit vmcnt(0)); `s_nop 1` keeps the data registers until the store has read them.
+typedef unsigned st4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(void* p, const st4u_t& r) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+}
+template <bool WT>
+__device__ __forceinline__ void store8_pub(bf16_t* p, const float8& v) {
+    if constexpr (WT) {
+        st4u_t r;
+        r[0] = (uint32_t)f2bf(v.lo.x) | ((uint32_t)f2bf(v.lo.y) << 16);
+        r[1] = (uint32_t)f2bf(v.lo.z) | ((uint32_t)f2bf(v.lo.w) << 16);
+        r[2] = (uint32_t)f2bf(v.hi.x) | ((uint32_t)f2bf(v.hi.y) << 16);
+        r[3] = (uint32_t)f2bf(v.hi.z) | ((uint32_t)f2bf(v.hi.w) << 16);
+        store16_wt(p, r);
+    } else store8(p, v);
+}
+template <bool WT>
+__device__ __forceinline__ void store8_pub(float* p, const float8& v) {
+    if constexpr (WT) {
+        store16_wt(p, __builtin_bit_cast(st4u_t, v.lo));
+        store16_wt(p + 4, __builtin_bit_cast(st4u_t, v.hi));
+    } else store8(p, v);
+}
+
+template <int BM, int BN, int NW, int MI, int NI, typename T = bf16_t, bool WT = false>
 __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
                                               int lane, int t, f32x4 (&acc)[MI][NI]) {
     constexpr int PITCH = BN * 4;
@@ -1261,7 +1288,7 @@ __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds,
             v.lo.x += o.lo.x; v.lo.y += o.lo.y; v.lo.z += o.lo.z; v.lo.w += o.lo.w;
             v.hi.x += o.hi.x; v.hi.y += o.hi.y; v.hi.z += o.hi.z; v.hi.w += o.hi.w;
         }
-        store8(p, v);
+        store8_pub<WT>(p, v);
     }
 }
 
@@ -1302,7 +1329,7 @@ __device__ __forceinline__ void epilogue_tile_slab(const mdm_gemm_desc& d, float
 // chunks = 512 or 256 active threads.  Same arithmetic as gn_bwd_reg_kernel (norm.hip); d(z) enters in fp32 instead of bf16.
 // LDS: [0, 16K) the fp32 tile, [16K, 80K) column-sum scratch [32 quantities][512], then small arrays.
 // ----------------------------------------------------------------------------
-template <int MI, int NI, int BN>
+template <int MI, int NI, int BN, bool WT = false>
 __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
                                                   int lane, int t, f32x4 (&acc)[MI][NI]) {
     constexpr int PITCH = BN * 4, NCH = BN / 8, NCH_SH = NCH == 8 ? 3 : 2, ACTIVE = 64 * NCH;
@@ -1410,7 +1437,7 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
             v.lo.x += old.lo.x; v.lo.y += old.lo.y; v.lo.z += old.lo.z; v.lo.w += old.lo.w;
             v.hi.x += old.hi.x; v.hi.y += old.hi.y; v.hi.z += old.hi.z; v.hi.w += old.hi.w;
         }
-        store8(p, v);
+        store8_pub<WT>(p, v);
     }
     if (d.gnb_sum_img || d.gnb_sum_all) {
         __syncthreads();
@@ -1440,7 +1467,7 @@ __device__ __forceinline__ void epilogue_tile_gnb(const mdm_gemm_desc& d, char* 
 // statistics over the ROUNDED values exactly as a separate GroupNorm launch would see them -- two passes (mean, then
 // centred squares: exact for constant maps like the pivot-shifted sums of norm.hip) -- and z = silu?(y_hat*gamma+beta).
 // ----------------------------------------------------------------------------
-template <int MI, int NI, int BN>
+template <int MI, int NI, int BN, bool WT = false>
 __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
                                                   int lane, int t, f32x4 (&acc)[MI][NI]) {
     constexpr int PITCH = BN * 4, NCH = BN / 8, NCH_SH = NCH == 8 ? 3 : 2, ACTIVE = 64 * NCH;
@@ -1482,7 +1509,7 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
             v.hi.x += b.hi.x; v.hi.y += b.hi.y; v.hi.z += b.hi.z; v.hi.w += b.hi.w;
         }
         bf16_t* yp = reinterpret_cast<bf16_t*>(d.D0) + (int64_t)m * d.ldd0 + n;
-        store8(yp, v);
+        store8_pub<WT>(yp, v);
         // the values as GroupNorm reads them back: rounded to bf16
         const float vv[8] = {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w};
 #pragma unroll
@@ -1546,7 +1573,7 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
             if (d.gnf_silu) o[e] = silu_f(o[e]);
         }
         const float8 zo = {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-        store8(reinterpret_cast<bf16_t*>(d.gnf_out) + (int64_t)m * C + n, zo);
+        store8_pub<WT>(reinterpret_cast<bf16_t*>(d.gnf_out) + (int64_t)m * C + n, zo);
     }
     const int ngt = BN >> cpg_sh;                                          // groups inside this BN-channel tile
     if (t < nimg * ngt) {
@@ -1580,7 +1607,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 
 // (device body: the kernel proper below, and one role of conv_pair_kernel.  bx / gx / bz stand for blockIdx.x / gridDim.x /
 // blockIdx.z of a launch of its own)
-template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false>
+template <int BM, int BN, int NSTAGE, int WR, int WC, int WK, bool PIPE = false, bool STAG = false, bool WT = false>
 __device__ __forceinline__ void conv_lin2_body(const mdm_gemm_desc& d, char* ring, const int bx, const int gx, const int bz) {
     constexpr int BK = 64, NW = WR * WC * WK;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -1846,11 +1873,11 @@ __device__ __forceinline__ void conv_lin2_body(const mdm_gemm_desc& d, char* rin
         if constexpr (BM == 64 && BN == 64 && WR == 4 && WC == 2 && WK == 1) {
             // 1x1 convolutions on 4x4 / 8x8 maps (the attention block's projections): a 64-row tile is whole images, like the
             // 64-pixel halo tiles -- the same fused GroupNorm epilogues apply (lin2_gn_tile)
-            if (d.gnb_x) epilogue_tile_gnb<MI, NI, 64>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
-            else if (d.gnf_out) epilogue_tile_gnf<MI, NI, 64>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
-            else epilogue_tile<BM, BN, NW, MI, NI>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+            if (d.gnb_x) epilogue_tile_gnb<MI, NI, 64, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+            else if (d.gnf_out) epilogue_tile_gnf<MI, NI, 64, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+            else epilogue_tile<BM, BN, NW, MI, NI, bf16_t, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
         } else
-        epilogue_tile<BM, BN, NW, MI, NI>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        epilogue_tile<BM, BN, NW, MI, NI, bf16_t, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -2547,7 +2574,7 @@ __device__ __forceinline__ void split_bf16_pair(f32x4& a, f32x4& b) {
 // channel slab is split ONCE, IN PLACE in LDS by all 512 threads during the last filter row of the slab in front of it (chunk g of a
 // 128-byte row becomes the 8 hi halves, chunk g ^ 4 the 8 lo halves of the same 8 channels: the fragment addresses do not change),
 // and the filter tiles arrive already split from the B_split shadow (mdm_split_shadow: same bytes, same arrangement).
-template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t, bool SPLIT = false>
+template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t, bool SPLIT = false, bool WT = false>
 __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx, const int m_base = 0) {
     static_assert(!SPLIT || sizeof(T) == 4, "conv_halo: SPLIT is the fp32-storage variant");
     constexpr int NW = 8, WR = 4, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
@@ -2783,11 +2810,11 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
     MDM_T(const unsigned long long t_loop_end = stamp_now();)
     __syncthreads();
     if constexpr (!F32 && BM == 64 && (BN == 64 || BN == 32)) {
-        if (d.gnb_x) epilogue_tile_gnb<MI, NI, BN>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
-        else if (d.gnf_out) epilogue_tile_gnf<MI, NI, BN>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
-        else epilogue_tile<BM, BN, NW, MI, NI>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        if (d.gnb_x) epilogue_tile_gnb<MI, NI, BN, WT>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);      // uniform
+        else if (d.gnf_out) epilogue_tile_gnf<MI, NI, BN, WT>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        else epilogue_tile<BM, BN, NW, MI, NI, bf16_t, WT>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
     } else {
-        epilogue_tile<BM, BN, NW, MI, NI, T>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
+        epilogue_tile<BM, BN, NW, MI, NI, T, WT>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc);
     }
 #ifdef MDM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2806,6 +2833,384 @@ template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     conv_halo_body<BM, NPW, BN, NSB, TG, T, SPLIT>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+
+
+// ----------------------------------------------------------------------------
+// epilogue_rows: the epilogue of conv_small_body in REGISTERS.  The waves' partial tiles pass through LDS once anyway (the k-split
+// reduction), so the reader is free to pick its own layout: wave g (of four) takes channels 8g .. 8g+7 of the 32-channel tile = ONE
+// GroupNorm group (C / G = 8), lane r takes pixel r of the 64-pixel tile -- a lane's eight values are exactly one 16-byte NHWC vector
+// (x, the residual, the destination and the normalised output are each one load / store per lane), and every GroupNorm sum is a sum
+// over the lanes of an image: wave shuffles, no LDS passes, no workgroup barriers.  The LDS epilogues this replaces on these tiles
+// (epilogue_tile_gnf / _gnb: ~12 barriers, two dependent rounds of column sums with 16-way bank conflicts) took 11 000 cycles behind a
+// loop of 11 000 (in-kernel stamps, profiles/r04_small_conv_stamps.txt).  Same arithmetic: statistics in two passes over the
+// bf16-rounded values (forward), the gn_bwd_reg_kernel formulas (backward); sums in a fixed (butterfly) order.
+// Requires C / G == 8 where a GroupNorm is fused, N0 % 8 == 0.  P16: 4x4 maps (an image = 16 lanes), else 8x8 (64 lanes).
+// ----------------------------------------------------------------------------
+template <bool P16>
+__device__ __forceinline__ float img_sum(float v) {                // sum over the lanes of one image, result in every lane of it
+#pragma unroll
+    for (int o = 1; o < (P16 ? 16 : 64); o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <bool P16>
+__device__ __forceinline__ float tile_sum_from_img(float v) {      // image sums -> sum over all 64 pixels of the tile
+    if constexpr (P16) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); }
+    return v;
+}
+__device__ __forceinline__ void unpack8(const float8& a, float (&o)[8]) {
+    o[0] = a.lo.x; o[1] = a.lo.y; o[2] = a.lo.z; o[3] = a.lo.w; o[4] = a.hi.x; o[5] = a.hi.y; o[6] = a.hi.z; o[7] = a.hi.w;
+}
+__device__ __forceinline__ float8 pack8(const float (&o)[8]) {
+    return {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+}
+__device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <bool WT, bool P16>
+__device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, const f32x4* red, const int m0, const int n0, const int g, const int r) {
+    constexpr int P = P16 ? 16 : 64, p_sh = P16 ? 4 : 6;
+    // pixel r, channels 8g .. 8g+7 of the tile: two accumulator quads of each of the four k-step partials (ascending k: fixed order)
+    const int ph = r >> 5, ti = ((r >> 4) & 1) * 2 + (g >> 1), l0 = (r & 15) + 32 * (g & 1);
+    float v[8];
+    {
+        const f32x4 a = red[((ph * 4) * 4 + ti) * 64 + l0], b = red[((ph * 4) * 4 + ti) * 64 + l0 + 16];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+        const f32x4 a = red[((ph * 4 + ks) * 4 + ti) * 64 + l0], b = red[((ph * 4 + ks) * 4 + ti) * 64 + l0 + 16];
+        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    const int64_t m = (int64_t)m0 + r;
+    const int n = n0 + 8 * g, C = d.N;
+    const int img = (m0 >> p_sh) + (P16 ? (r >> 4) : 0);
+    const bool first = (r & (P - 1)) == 0;                          // the lane that writes per-image results
+    const float inv_cnt = 1.f / (8.f * (float)P);
+    if (d.gnb_x) {
+        // ---- GroupNorm backward of the tensor this convolution's input came from (mdm_gemm_can_fuse_gn_bwd: no bias / row / residual)
+        const int G = d.gnb_G;
+        float x[8], ga[8], be[8], gz[8], xh[8], o[8];
+        unpack8(load8(reinterpret_cast<const bf16_t*>(d.gnb_x) + m * C + n), x);
+        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + (n >> 3)) * 2);
+        load8f(d.gnb_gamma + n, ga);
+        load8f(d.gnb_beta + n, be);
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xh[e] = (x[e] - st.x) * st.y;
+            gz[e] = v[e];
+            if (d.gnb_silu) gz[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
+            a1 += gz[e] * ga[e];
+            a2 += gz[e] * ga[e] * xh[e];
+        }
+        a1 = img_sum<P16>(a1);
+        a2 = img_sum<P16>(a2);
+        const float k1 = st.y * a1 * inv_cnt, k2 = st.y * a2 * inv_cnt;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = st.y * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
+        // dgamma / dbeta: sums over every pixel of the tile; lane e adds dgamma[n + e], lane 8 + e dbeta[n + e] (one atomic per
+        // channel per workgroup, as before)
+        float mine = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dg = tile_sum_from_img<P16>(img_sum<P16>(gz[e] * xh[e])), db = tile_sum_from_img<P16>(img_sum<P16>(gz[e]));
+            mine = r == e ? dg : (r == 8 + e ? db : mine);
+        }
+        if (r < 16) atomicAdd((r < 8 ? d.gnb_dgamma : d.gnb_dbeta) + n + (r & 7), mine);
+        if (d.gnb_sum_img || d.gnb_sum_all) {                       // uniform: column sums of dx (before any accumulation)
+            float cs[8], tot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cs[e] = img_sum<P16>(o[e]);
+                const float tt = tile_sum_from_img<P16>(cs[e]);
+                tot = r == e ? tt : tot;
+            }
+            if (d.gnb_sum_img && first) {                           // this workgroup owns (image, channel)
+                float* sp = d.gnb_sum_img + (int64_t)img * d.gnb_sum_ld + n;
+                *reinterpret_cast<float4*>(sp) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                *reinterpret_cast<float4*>(sp + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+            }
+            if (d.gnb_sum_all && r < 8) atomicAdd(d.gnb_sum_all + n + r, tot);
+        }
+        bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n;
+        if (d.acc0) {
+            float old[8];
+            unpack8(load8(p), old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        if (d.gnb_add) {
+            float old[8];
+            unpack8(load8(reinterpret_cast<const bf16_t*>(d.gnb_add) + m * d.ldd0 + n), old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        store8_pub<WT>(p, pack8(o));
+        return;
+    }
+    // ---- forward-type epilogue: scale, bias, time-embedding row, residual, accumulate; optionally the GroupNorm of the result
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+    if (d.bias) {
+        float b[8];
+        load8f(d.bias + n, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    if (d.rowvec) {
+        float b[8];
+        load8f(d.rowvec + (int64_t)div_rows((int)m, d.rows_per_img) * d.rv_ld + n, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    if (d.resid) {
+        float b[8];
+        unpack8(load8(reinterpret_cast<const bf16_t*>(d.resid) + m * d.ldr + n), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    bf16_t* p; int accf;
+    if (n < d.N0) { p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n; accf = d.acc0; }
+    else          { p = reinterpret_cast<bf16_t*>(d.D1) + m * d.ldd1 + (n - d.N0); accf = d.acc1; }
+    if (accf) {
+        float old[8];
+        unpack8(load8(p), old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += old[e];
+    }
+    store8_pub<WT>(p, pack8(v));
+    if (d.gnf_out) {
+        const int G = d.gnf_G;
+        float y[8], ga[8], be[8], o[8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { y[e] = bf2f(f2bf(v[e])); s1 += y[e]; }       // the values as a GroupNorm launch would read them back
+        const float mean = img_sum<P16>(s1) * inv_cnt;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float c0 = y[e] - mean; s2 += c0 * c0; }
+        const float rstd = rsqrtf(img_sum<P16>(s2) * inv_cnt + d.gnf_eps);
+        load8f(d.gnf_gamma + n, ga);
+        load8f(d.gnf_beta + n, be);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = fmaf((y[e] - mean) * rstd, ga[e], be[e]);
+            if (d.gnf_silu) o[e] = silu_f(o[e]);
+        }
+        store8_pub<WT>(reinterpret_cast<bf16_t*>(d.gnf_out) + m * C + n, pack8(o));
+        if (first) {
+            float* sp = d.gnf_stats + ((int64_t)img * G + (n >> 3)) * 2;
+            sp[0] = mean; sp[1] = rstd;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// conv_small: the 3x3 stride-1 "same" convolutions of the 4x4 / 8x8 maps (forward incl. the folded x2 upsample, and the data gradient
+// through the transposed shadow) with the REDUCTION split over the waves.  On conv_halo_body's 64 x 32 tiles of these maps every wave
+// owns ONE 16 x 16 accumulator: per filter tap it reads four fragments for two MFMAs that wait for each other, and the in-kernel
+// stamps put the loop at 430 cycles per tap (15 500 cycles for a 256 -> 256 layer: 14 B/clk of operands against the CU's ~27 B/clk
+// intake, 7 % of the matrix pipe; profiles/r04_chain_stamps.txt).  Here the tile is the same (64 pixels = whole images x 32 output
+// channels, so the fused GroupNorm epilogues apply unchanged) but a channel "superslab" is 128 channels = four 32-deep k-steps:
+//   wave = (ks, ph): k-step ks of the superslab, pixel half ph -> 2 x 2 accumulator tiles per wave, four INDEPENDENT MFMAs per tap
+//   from four fragments, 12 MFMAs per barrier (3 taps); the 8 waves' partial sums meet in LDS once, behind the loop, in a fixed order.
+//   LDS: two halo buffers (the (OH+2) x (OW+2) halo of a 128-channel superslab, 256-byte pixel rows, 16-byte chunks XOR-swizzled by
+//   the row), a three-stage ring of filter stages (3 taps x 32 rows x 256 B = 24 KiB each), refilled two groups ahead; the halo of
+//   superslab s+1 arrives during the first two groups of superslab s.  Every wave issues the same number of LDS-DMA operations per
+//   group (missing pieces go to a dummy page), so the waits are compile-time vmcnt counts.
+// Requires what halo_tile() == 64 requires, and C0 % 128 == C1 % 128 == 0, N % 32 == 0.
+// ----------------------------------------------------------------------------
+#ifndef MDM_SMALL_EPI
+#define MDM_SMALL_EPI 1             // 0: conv_small keeps the LDS epilogues of the halo tiles (A/B builds)
+#endif
+template <int NPW, bool WT = false>
+__device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
+    constexpr int BN = 32, CS = 128, NSB = 3;
+    constexpr int ROWB = CS * 2, B_TAP = BN * ROWB, STAGE_B = 3 * B_TAP;
+    constexpr int HA = (NPW + 1) / 2, HB = NPW - HA;                // halo pieces a wave issues in group 0 / group 1 of a superslab
+    MDM_T(const unsigned long long t_entry = stamp_now();)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ks = wave & 3, ph = wave >> 2;
+    const int OW = d.OW, OH = d.OH, HW2 = OW + 2;
+    const int ow_sh = __builtin_ctz(OW), p_sh = ow_sh + __builtin_ctz(OH);
+    const int IMGS = 64 >> p_sh;                                     // whole images per tile: 4 (4x4) or 1 (8x8)
+    const int HRI = (OH + 2) * HW2, HR = IMGS * HRI, NPA = (HR + 3) >> 2, ABUF = NPA * 1024;
+    const float inv_hw2 = __builtin_amdgcn_rcpf((float)HW2), inv_hri = __builtin_amdgcn_rcpf((float)HRI);
+    char* const bring = lds + 2 * ABUF;
+    char* const dummy = bring + NSB * STAGE_B;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int bid = xcd_remap(bx, gx);
+    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * 64;
+    const int img0 = m0 >> p_sh;
+    const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
+    const int NSS = d.Ck / CS;
+    const int sgn = d.transposed ? -1 : 1;
+
+    // ---- halo pieces of this wave: piece p = wave + 8 k holds halo rows 4p .. 4p+3 (256 B each); lane -> (row, chunk position)
+    int apix[NPW], a_lch[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int hr = (wave + 8 * k) * 4 + (lane >> 4);
+        const int il = (int)(((float)hr + 0.5f) * inv_hri), hrem = hr - il * HRI;
+        const int hy = (int)(((float)hrem + 0.5f) * inv_hw2), hx = hrem - hy * HW2;
+        const int y = hy - 1, x = hx - 1;
+        const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M;
+        apix[k] = ok ? (((img0 + il) * (OH >> d.ups) + (y >> d.ups)) * (OW >> d.ups) + (x >> d.ups)) : -1;
+        a_lch[k] = ((lane & 15) ^ (hr & 15)) << 4;                  // position c of row hr holds source chunk c ^ (hr & 15)
+    }
+    auto issue_a = [&](int k, int ss, char* abuf) {                 // k compile-time after unrolling
+        const int p = wave + 8 * k;
+        const int c = ss * CS;
+        const bool s1 = c >= d.C0;
+        const bf16_t* S = reinterpret_cast<const bf16_t*>(s1 ? d.src1 : d.src0);
+        const int ld = s1 ? d.ld1 : d.ld0, cc = s1 ? c - d.C0 : c;
+        const char* src = reinterpret_cast<const char*>(S + (int64_t)apix[k] * ld + cc) + a_lch[k];
+        lds_dma16((apix[k] >= 0 && ss < NSS) ? src : zlane, p < NPA ? abuf + p * 1024 : dummy);
+    };
+    // ---- filter tile of (tap, superslab): 32 rows (output channels) x 256 B = 8 pieces, one per wave
+    const int bn_l = 4 * wave + (lane >> 4);
+    const bool b_live = n0 + bn_l < d.N;
+    const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(n0 + bn_l) * d.ldb) +
+                        (((lane & 15) ^ (bn_l & 15)) << 4);
+    // (Measured and NOT kept: the six dummy DMA slots of the last two groups TOUCHING what the epilogue is going to load -- x / residual,
+    //  the destination of an accumulate, the extra addend -- so that those cold lines are in L2 by then: the epilogue got 450 cycles
+    //  shorter, the loop 2 000 longer (its final vmcnt(0) then waits for HBM): 3.703 -> 3.738 ms/step.)
+    auto issue_b = [&](int tap, int ss, int lds_off) {
+        const int64_t off = ((int64_t)tap * d.wtap + (int64_t)ss * CS) * 2;
+        const bool live = ss < NSS && b_live;
+        lds_dma16(live ? b_row + off : zlane, ss < NSS ? bring + lds_off + wave * 1024 : dummy);
+    };
+
+    // ---- prologue: halo of superslab 0, filter groups 0 and 1
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) issue_a(k, 0, lds);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) issue_b(k, 0, k * B_TAP);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) issue_b(3 + k, 0, STAGE_B + k * B_TAP);
+
+    // ---- fragment addresses: centre-tap halo row of this lane's pixel in each of its two 16-row blocks; filter rows
+    const int kch = ks * 4 + (lane >> 4);                           // 16-byte chunk of this lane inside a 256-byte row
+    int a_hb[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = ph * 32 + i * 16 + (lane & 15);
+        const int il = ml >> p_sh, mrem = ml - (il << p_sh);
+        const int r = mrem >> ow_sh, x = mrem - (r << ow_sh);
+        a_hb[i] = il * HRI + (r + 1) * HW2 + x + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nl = j * 16 + (lane & 15);
+        b_off[j] = nl * ROWB + ((kch ^ (nl & 15)) << 4);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int stage = 0;
+    MDM_T(unsigned long long t_wait = 0, t_bar = 0;)
+    MDM_T(const unsigned long long tstart = stamp_now();)
+#define MDM_SMALL_GROUP(G3)                                                                                        \
+    {                                                                                                              \
+        MDM_T(const unsigned long long tw0 = stamp_now();)                                                         \
+        wait_vmcnt<(G3) == 0 ? 3 : ((G3) == 1 ? 3 + HA : 3 + NPW)>();                                              \
+        MDM_T(const unsigned long long tw1 = stamp_now(); t_wait += tw1 - tw0;)                                    \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        MDM_T(t_bar += stamp_now() - tw1;)                                                                         \
+        const int rs = stage + 2 >= NSB ? stage + 2 - NSB : stage + 2;                                             \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                              \
+            issue_b((((G3) + 2) % 3) * 3 + k, ss + ((G3) + 2) / 3, rs * STAGE_B + k * B_TAP);                      \
+        if ((G3) == 0) { _Pragma("unroll") for (int q = 0; q < HA; ++q) issue_a(q, ss + 1, anext); }               \
+        if ((G3) == 1) { _Pragma("unroll") for (int q = 0; q < HB; ++q) issue_a(HA + q, ss + 1, anext); }          \
+        const char* Bs = bring + stage * STAGE_B;                                                                  \
+        bf16x8 af[3][2], bfr[3][2];                                                                                \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                            \
+            const int tx = k, ty = (G3);                                                                           \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                bfr[k][j] = *reinterpret_cast<const bf16x8*>(Bs + k * B_TAP + b_off[j]);                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+                const int hr = a_hb[i] + sgn * ((ty - 1) * HW2 + (tx - 1));                                        \
+                af[k][i] = *reinterpret_cast<const bf16x8*>(acur + hr * ROWB + ((kch ^ (hr & 15)) << 4));          \
+            }                                                                                                      \
+        }                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                              \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[k][j], af[k][i], acc[i][j], 0, 0, 0);  \
+        stage = stage + 1 == NSB ? 0 : stage + 1;                                                                  \
+    }
+    for (int ss = 0; ss < NSS; ++ss) {
+        const char* const acur = lds + (ss & 1) * ABUF;
+        char* const anext = lds + ((ss + 1) & 1) * ABUF;
+        MDM_SMALL_GROUP(0) MDM_SMALL_GROUP(1) MDM_SMALL_GROUP(2)
+    }
+#undef MDM_SMALL_GROUP
+    wait_vmcnt<0>();
+    MDM_T(const unsigned long long t_loop_end = stamp_now();)
+    __syncthreads();
+    // ---- the waves' partial sums meet in LDS: wave (ks, ph) parks its 2 x 2 tiles, wave (wr, wc) of the epilogue layout adds the four
+    // k-steps of ITS 16 x 16 tile in ascending order (fixed summation order); the scratch sits behind the epilogue's fp32 tile
+    {
+        f32x4* red = reinterpret_cast<f32x4*>(lds + 16384);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) red[(wave * 4 + i * 2 + j) * 64 + lane] = acc[i][j];
+        __syncthreads();
+        // C / G == 8 (or no fused GroupNorm): the register epilogue, four waves; anything else: the LDS epilogues of the halo tiles
+        const int cpg = d.gnb_x ? d.N / d.gnb_G : (d.gnf_out ? d.N / d.gnf_G : 8);
+        if (MDM_SMALL_EPI && cpg == 8 && (d.N0 & 7) == 0) {                                                         // uniform
+            if (wave < 4) {
+                if (p_sh == 4) epilogue_rows<WT, true>(d, red, m0, n0, wave, lane);
+                else epilogue_rows<WT, false>(d, red, m0, n0, wave, lane);
+            }
+        } else {
+        const int wr = wave >> 1, wc = wave & 1;
+        const int src = (wr >> 1) * 4, tile = (wr & 1) * 2 + wc;
+        f32x4 v = red[((src + 0) * 4 + tile) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const f32x4 o = red[((src + q) * 4 + tile) * 64 + lane];
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        f32x4 one[1][1];
+        one[0][0] = v;
+        if (d.gnb_x) epilogue_tile_gnb<1, 1, BN, WT>(d, lds, m0, n0, wr * 16, wc * 16, lane, t, one);          // uniform
+        else if (d.gnf_out) epilogue_tile_gnf<1, 1, BN, WT>(d, lds, m0, n0, wr * 16, wc * 16, lane, t, one);
+        else epilogue_tile<64, BN, 8, 1, 1, bf16_t, WT>(d, lds, m0, n0, wr * 16, wc * 16, lane, t, one);
+        }
+    }
+#ifdef MDM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const unsigned widx = (unsigned)bx * 8 + wave;
+        if (widx < 4096) {
+            unsigned long long* r = g_stamp_buf + widx * 32;
+            r[0] = t_wait; r[1] = t_bar; r[2] = 0; r[3] = 0; r[4] = NSS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
+            r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
+        }
+    }
+#endif
+}
+
+template <int NPW>
+__global__ __launch_bounds__(512) void conv_small_kernel(mdm_gemm_desc d) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    conv_small_body<NPW>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+// conv_small + a 1x1 projection in one launch (the pairs of mdm_gemm_pair on the 4x4 / 8x8 maps)
+template <int NPW>
+__global__ __launch_bounds__(512) void conv_pair_small_kernel(mdm_gemm_desc a, mdm_gemm_desc b, int na) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    if ((int)blockIdx.x < na) conv_small_body<NPW>(a, lds, (int)blockIdx.x, na);
+    else conv_lin2_body<64, 64, 4, 4, 2, 1, true, false>(b, lds, (int)blockIdx.x - na, (int)gridDim.x - na, 0);
 }
 
 // Two tile sizes in one launch (split products, sample_num = 100): a 32x32 layer is 800 tiles of 256 pixels on 256 CUs -- 3.1 rounds of
@@ -3043,6 +3448,13 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(mdm_gemm_desc a, mdm_gem
 //   workgroups resident (grid <= CUs: one workgroup per CU by its LDS request) the earliest unfinished block is never blocked.  The
 //   spin is bounded all the same: on a timeout the error word is set and the launch ends (with wrong results) instead of hanging.
 // ----------------------------------------------------------------------------
+#ifndef MDM_CHAIN_RELEASE_FENCE
+#define MDM_CHAIN_RELEASE_FENCE 1           // 1: an agent-scope release (L2 write-back) per block before its arrivals
+#endif
+#ifndef MDM_CHAIN_WT
+#define MDM_CHAIN_WT 0                      // 1: the tile stores of a chain's phases write through (sc1); without the release an
+                                            //    intermittent mismatch was observed (profiles/r04_chain_findings.md): not the default
+#endif
 struct ChainPhase {
     int kind[2];            // role 0 / role 1 (mdm_gemm_pair): 0 = halo 64x32 (2 pieces per wave), 1 = halo 64x32 (3 pieces), 2 = lin2 64x64, -1 = none
     int desc[2];
@@ -3097,19 +3509,24 @@ __global__ __launch_bounds__(512) void chain_kernel(const mdm_gemm_desc* __restr
             {
                 const mdm_gemm_desc d = descs[P.desc[role]];
                 const int kind = P.kind[role];
-                if (kind == 0) conv_halo_body<64, 2, 32, 3, 3>(d, lds, bx, gx);
-                else if (kind == 1) conv_halo_body<64, 3, 32, 3, 3>(d, lds, bx, gx);
-                else conv_lin2_body<64, 64, 4, 4, 2, 1, true, false>(d, lds, bx, gx, 0);
+                constexpr bool WT = MDM_CHAIN_WT != 0;      // tile stores write through (store8_pub)
+                if (kind == 0) conv_halo_body<64, 2, 32, 3, 3, bf16_t, false, WT>(d, lds, bx, gx);
+                else if (kind == 1) conv_halo_body<64, 3, 32, 3, 3, bf16_t, false, WT>(d, lds, bx, gx);
+                else if (kind == 3) conv_small_body<4, WT>(d, lds, bx, gx);
+                else if (kind == 4) conv_small_body<5, WT>(d, lds, bx, gx);
+                else conv_lin2_body<64, 64, 4, 4, 2, 1, true, false, WT>(d, lds, bx, gx, 0);
             }
             MDM_T(const unsigned long long t_b1 = stamp_now();)
             // publish: every wave's stores have been acknowledged, then one release for the workgroup, then the arrivals
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // (also: the next block may refill the LDS)
             if (t < 64) {
-                if (t == 0) {
+#if MDM_CHAIN_RELEASE_FENCE
+                if (t == 0) {                                   // (plain tile stores + L2 write-back: measured +9 us per hand-off)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+#endif
                 if (t < nimg) __hip_atomic_fetch_add(mine + img0 + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #ifdef MDM_STAMP
@@ -3261,6 +3678,23 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // TG = 3: 
     }
     dim3 grid((unsigned)((int64_t)(d.M / BM) * cdiv(d.N, BN)));
     hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T, SPLIT>), grid, dim3(512), bytes, s, d);
+    return 0;
+}
+static int small_pieces(const mdm_gemm_desc& d) {           // 1-KiB pieces of one conv_small halo buffer (256-byte pixel rows)
+    const int imgs = 64 / (d.OH * d.OW);
+    return (imgs * (d.OH + 2) * (d.OW + 2) + 3) / 4;
+}
+static int small_lds_bytes(const mdm_gemm_desc& d) { return 2 * small_pieces(d) * 1024 + 3 * 3 * 32 * 256 + 1024; }
+template <int NPW>
+static int launch_small(const mdm_gemm_desc& d, hipStream_t s) {
+    const int bytes = small_lds_bytes(d);
+    MDM_REQUIRE(small_pieces(d) <= 8 * NPW && bytes <= 160 * 1024 && bytes >= 16384 + 65536 + 4096 + 512, "conv_small: tile does not fit (%d bytes)", bytes);
+    static int configured = 0;
+    if (configured < bytes) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = bytes;
+    }
+    hipLaunchKernelGGL((conv_small_kernel<NPW>), dim3((unsigned)((int64_t)(d.M / 64) * cdiv(d.N, 32))), dim3(512), bytes, s, d);
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
@@ -3543,7 +3977,11 @@ static bool lin2_gn_tile(const mdm_gemm_desc& d) {
            d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N0 % 8 == 0 && !d.out_f32 && d.splitk <= 1;
 }
 enum ConvVar { CV_NONE = 0, CV_H256_4, CV_H256_6, CV_H128_3, CV_H128_4, CV_H128_6, CV_H64_2_32, CV_H64_3_32, CV_H64_2_64, CV_H64_3_64,
-               CV_L128, CV_L64x128, CV_L64 };
+               CV_L128, CV_L64x128, CV_L64, CV_S64_4, CV_S64_5 };
+#ifndef MDM_SMALL_CONV
+#define MDM_SMALL_CONV 1            // 0: the 4x4 / 8x8 maps stay on conv_halo_body's 64 x 32 tiles (A/B builds)
+#endif
+
 static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned grid_z) {
     if (!(d.dtype == MDM_BF16 && ring_eligible(d) && d.layout == 0 && d.conv &&
           (d.stride == 1 || (d.stride == 2 && !d.transposed && d.ups == 0)) && d.C0 <= 4096 && d.C1 <= 4096 &&
@@ -3555,7 +3993,12 @@ static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned 
         const int npw = (halo_pieces(hb, d.OH, d.OW) + 7) / 8;      // halo pieces per wave
         if (hb == 256) return npw <= 4 ? CV_H256_4 : CV_H256_6;
         if (hb == 128) return npw <= 3 ? CV_H128_3 : npw <= 4 ? CV_H128_4 : CV_H128_6;
-        if (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32)) return npw <= 2 ? CV_H64_2_32 : CV_H64_3_32;
+        if (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32)) {
+            // 128-channel superslabs with the reduction split over the waves (conv_small_body) where the channel counts allow
+            const int spw = (small_pieces(d) + 7) / 8;
+            if (MDM_SMALL_CONV && d.Ck % 128 == 0 && d.C0 % 128 == 0 && d.C1 % 128 == 0 && spw <= 5) return spw <= 4 ? CV_S64_4 : CV_S64_5;
+            return npw <= 2 ? CV_H64_2_32 : CV_H64_3_32;
+        }
         return npw <= 2 ? CV_H64_2_64 : CV_H64_3_64;
     }
     if ((d.gnb_x || d.gnf_out) && lin2_gn_tile(d)) return CV_L64;      // the fused epilogues live on the 64 x 64 tile
@@ -3663,6 +4106,8 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             case CV_H64_3_32: rc = launch_halo<64, 3, 3, 32>(d, s); break;
             case CV_H64_2_64: rc = launch_halo<64, 2, 3>(d, s); break;
             case CV_H64_3_64: rc = launch_halo<64, 3, 3>(d, s); break;
+            case CV_S64_4: rc = launch_small<4>(d, s); break;
+            case CV_S64_5: rc = launch_small<5>(d, s); break;
             case CV_L128: rc = launch_lin2<128, 128, 3, 4, 2>(d, grid, s); break;
             case CV_L64x128: rc = launch_lin2<64, 128, 3, 2, 4>(d, g2, s); break;
             default: rc = launch_lin2<64, 64, 4, 4, 2>(d, grid, s); break;
@@ -3716,7 +4161,7 @@ struct Chain {
     unsigned* cnt_dev = nullptr;            // [n_ph][n_img] arrival counters + 4 words (error, spare)
     int n_ph = 0, n_img = 0, grid = 0, lds_bytes = 0;
 };
-// 0 = halo 64x32 with 2 pieces per wave, 1 = with 3, 2 = lin2 64x64, -1 = not a chain link
+// 0 = halo 64x32 with 2 pieces per wave, 1 = with 3, 2 = lin2 64x64, 3 / 4 = conv_small with 4 / 5 pieces, -1 = not a chain link
 static int chain_kind(const mdm_gemm_desc* dh, Resolved& r, int* lds_bytes) {
     if (resolve(dh, false, r)) return -1;
     const mdm_gemm_desc& d = r.d;
@@ -3735,6 +4180,10 @@ static int chain_kind(const mdm_gemm_desc* dh, Resolved& r, int* lds_bytes) {
         if (NPA > 8 * (cv == CV_H64_2_32 ? 2 : 3)) return -1;
         *lds_bytes = bytes;
         return cv == CV_H64_2_32 ? 0 : 1;
+    }
+    if (cv == CV_S64_4 || cv == CV_S64_5) {
+        *lds_bytes = small_lds_bytes(d);
+        return cv == CV_S64_4 ? 3 : 4;
     }
     if (cv == CV_L64 && r.tiles < (1ll << 20)) {
         int bytes = 4 * (64 + 64) * 64 * 2;                                        // as launch_lin2<64, 64, 4, 4, 2>
@@ -3773,6 +4222,22 @@ static int launch_pair(const mdm_gemm_desc& a, const mdm_gemm_desc& b, int nb, h
     return 0;
 }
 
+template <int NPW>
+static int launch_pair_small(const mdm_gemm_desc& a, const mdm_gemm_desc& b, int nb, hipStream_t s) {
+    int bytes = small_lds_bytes(a);
+    constexpr int lin_bytes = 4 * (64 + 64) * 64 * 2;
+    if (bytes < lin_bytes) bytes = lin_bytes;
+    MDM_REQUIRE(small_pieces(a) <= 8 * NPW && bytes <= 160 * 1024, "conv_pair_small: tile does not fit (%d bytes)", bytes);
+    static int configured = 0;
+    if (configured < bytes) {
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_small_kernel<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = bytes;
+    }
+    const int na = (int)((int64_t)(a.M / 64) * (a.N / 32));
+    hipLaunchKernelGGL((conv_pair_small_kernel<NPW>), dim3((unsigned)(na + nb)), dim3(512), bytes, s, a, b, na);
+    return 0;
+}
+
 extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b_host, void* stream) {
     hipStream_t s = pick_stream(stream);
     Resolved ra, rb;
@@ -3789,7 +4254,9 @@ extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b
     int rc = -2;
     if (b_plain && za == 1) {
         const int nb64 = (int)rb.tiles, nb64x128 = (int)((int64_t)cdiv(b.M, 64) * cdiv(b.N, 128));
-        if (va == CV_H64_2_32 && vb == CV_L64) rc = launch_pair<64, 2, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
+        if (va == CV_S64_4 && vb == CV_L64) rc = launch_pair_small<4>(a, b, nb64, s);
+        else if (va == CV_S64_5 && vb == CV_L64) rc = launch_pair_small<5>(a, b, nb64, s);
+        else if (va == CV_H64_2_32 && vb == CV_L64) rc = launch_pair<64, 2, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H64_3_32 && vb == CV_L64) rc = launch_pair<64, 3, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H128_3 && vb == CV_L64x128) rc = launch_pair<128, 3, 64, 3, 64, 128, 3, 2, 4>(a, b, nb64x128, s);
         else if (va == CV_H128_3 && vb == CV_L64) rc = launch_pair<128, 3, 64, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
@@ -3814,7 +4281,7 @@ extern "C" int mdm_chain_accepts(const mdm_gemm_desc* a_host, const mdm_gemm_des
     if (!b_host) return 1;
     const int kb = chain_kind(b_host, rb, &lb);
     // a pair = a halo convolution + a 1x1 projection without a fused GroupNorm epilogue (what mdm_gemm_pair fuses), same batch and map
-    return (ka <= 1 && kb == 2 && !rb.d.gnb_x && !rb.d.gnf_out && ra.d.M == rb.d.M && ra.d.OH == rb.d.OH && ra.d.OW == rb.d.OW) ? 1 : 0;
+    return (ka != 2 && kb == 2 && !rb.d.gnb_x && !rb.d.gnf_out && ra.d.M == rb.d.M && ra.d.OH == rb.d.OH && ra.d.OW == rb.d.OW) ? 1 : 0;
 }
 extern "C" int mdm_chain_create(const mdm_gemm_desc* descs_host, const int* roles, int n_phases, void* dev_buf, int64_t dev_bytes,
                                 int64_t* need_bytes_out, void** handle_out) {

@@ -68,7 +68,12 @@ def main():
         relG = float((ref[gi].double() - got[gi].double()).norm() / (ref[gi].double().norm() + 1e-30))
         print(f"{tag}: chained == per-layer launches on {len(bufs) - len(strict_bad)} of {len(bufs)} buffers bit for bit; rel-L2 of G {relG:.2e}; "
               f"status {[c.status() for c in ch.chains]}", flush=True)
-        assert not strict_bad, strict_bad[:8]
+        names = [a.name for a in model.acts[1:]] + ["d:" + a.name for a in model.acts if a.grad is not None and a is not model.y_out] + ["G"]
+        for i in strict_bad[:12]:
+            df = (ref[i].float() - got[i].float()).abs()
+            print(f"   MISMATCH {names[i]} {tuple(ref[i].shape)}: {int((df > 0).sum())} elements, max {float(df.max()):.3e}, first at {int((df.reshape(-1) > 0).nonzero()[0])}")
+        if os.environ.get("CHAIN_PROBE_STRICT", "1") == "1":
+            assert not strict_bad, strict_bad[:8]
         assert all(c.status() == 0 for c in ch.chains)
         g0, g1 = _lib.GraphExec(plan), _lib.GraphExec(ch)
         t0 = timed(g0, reps); t1 = timed(g1, reps); t0b = timed(g0, reps); t1b = timed(g1, reps)
@@ -76,5 +81,68 @@ def main():
         assert all(c.status() == 0 for c in ch.chains)
 
 
+def stamps():
+    """Stamped build (make EXTRA=-DMDM_STAMP, selected with MDM_LIB_PATH): cycles of wait / body / publish per block of the
+    longest chain of the forward plan, launched alone after a full forward.  `python scripts/chain_probe.py 32 0 stamps`"""
+    import ctypes
+    import numpy as np
+    N = int(sys.argv[1])
+    torch.cuda.set_device(0)
+    model = mdm.UNet(mdm.unet6_config(32), N=N, H=32, W=32, dtype=mdm.BF16, seed=0)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(N, 32, 32, model.cin_p, generator=g) * 2 - 1).to(model.device, torch.bfloat16)
+    x[..., model.cin:] = 0
+    model.x_in.data.copy_(x)
+    model.t_in.copy_(torch.randint(1, 1000, (N,), generator=g).float())
+    lib = _lib.load()
+    fn = lib.mdm_debug_stamps_n
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int, ctypes.c_int]
+    NREC = 32768
+    for tag, plan in (("fwd", model.forward_plan), ("bwd", model.backward_plan)):
+        ch = _lib.chained(plan, model.device)
+        ch.run(); ch.run()
+        torch.cuda.synchronize()
+        c = max(ch.chains, key=lambda c: c.n)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            _lib.check(lib.mdm_chain_launch(c.handle, st))
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * (NREC * 32))()
+        assert fn(buf, NREC, 1) == 0
+        _lib.check(lib.mdm_chain_launch(c.handle, st))
+        torch.cuda.synchronize()
+        assert fn(buf, NREC, 1) == 0
+        full = np.frombuffer(buf, dtype=np.uint64).reshape(NREC, 32)
+        body = full[:4096]
+        body = body[body[:, 5] > 0].astype(np.int64)
+        if len(body):        # the bodies' own records (last writer wins: the chain's last phases): per wave
+            md = lambda k: int(np.median(body[:, k]))
+            print(f"{tag}: body stamps over {len(body)} waves (median): entry->loop {md(8)}  loop {md(6)} ({md(4)} taps: vmcnt wait {md(0)}, barrier {md(1)})  "
+                  f"loop end->body end {md(9)}")
+        a = full[16384:]
+        t_first = None
+        print(f"{tag}: chain of {c.n} phases, status {c.status()}  (cycles of s_memtime; ~2.1 GHz under load, 100 MHz if the counter is the constant one)")
+        for p in range(c.n):
+            r = a[p * 512:(p + 1) * 512]
+            r = r[r[:, 6] > 0].astype(np.int64)
+            if not len(r):
+                continue
+            xcd = r[:, 4] >> 32                       # s_memtime counters of different XCDs are not aligned: spans from ONE XCD
+            r0 = r[xcd == xcd[0]] if t_first is None else r[xcd == xcd_ref]
+            if t_first is None:
+                xcd_ref = xcd[0]
+            if not len(r0):
+                continue
+            t_first = int(r0[:, 0].min()) if t_first is None else t_first
+            span = (int(r0[:, 0].min()) - t_first, int(r0[:, 2].min()) - t_first, int(r0[:, 3].max()) - t_first)
+            wait, body, pub = r[:, 1] - r[:, 0], r[:, 2] - r[:, 1], r[:, 3] - r[:, 2]
+            f = lambda v: f"{int(np.min(v)):6d} {int(np.median(v)):6d} {int(np.max(v)):6d}"
+            print(f"  phase {p}: {len(r):3d} blocks  start {span[0]:7d}  first body end {span[1]:7d}  "
+                  f"end {span[2]:7d} | wait {f(wait)} | body {f(body)} | publish {f(pub)}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "stamps":
+        stamps()
+        sys.exit(0)
     main()

@@ -750,6 +750,8 @@ def test_grouped_weight_gradients_match_self_contained_ones():
 
 
 @pytest.mark.parametrize("case", [(8, 8, 256, 256, True, False), (16, 4, 128, 256, True, True), (4, 8, 128, 64, False, False),
+                                  # conv_small_body + its register epilogue (128-channel superslabs, C / G = 8): with the column sums, without SiLU
+                                  (32, 4, 256, 256, True, True), (8, 8, 256, 512, True, True), (12, 4, 256, 256, False, False),
                                   (8, 8, 512, 256, True, True), (4, 4, 2048, 64, True, False),       # 64-channel groups -> 64-wide tiles
                                   (8, 8, 256, 768, False, False, 1), (16, 4, 256, 768, False, False, 1)])   # 1x1 convolutions (conv_lin2 tiles)
 def test_groupnorm_backward_fused_into_the_data_gradient(case):
@@ -802,6 +804,7 @@ def test_groupnorm_backward_fused_into_the_data_gradient(case):
 
 
 @pytest.mark.parametrize("case", [(8, 8, 128, 256, True), (16, 4, 256, 128, True), (4, 8, 64, 512, False),
+                                  (32, 4, 256, 256, True), (8, 8, 512, 256, False), (12, 4, 128, 256, True),        # conv_small_body + register epilogue
                                   (4, 4, 64, 2048, True),                                           # 64-channel groups -> 64-wide tiles
                                   (8, 8, 256, 256, False, 1), (16, 4, 256, 256, True, 1)])          # 1x1 convolutions (conv_lin2 tiles)
 def test_groupnorm_forward_fused_into_the_producing_conv(case):
