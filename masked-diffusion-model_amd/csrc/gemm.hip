@@ -1583,6 +1583,179 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
     }
 }
 
+// ----------------------------------------------------------------------------
+// epilogue_rows: the epilogue of conv_small_body in REGISTERS.  The waves' partial tiles pass through LDS once anyway (the k-split
+// reduction), so the reader is free to pick its own layout: wave g (of four) takes channels 8g .. 8g+7 of the 32-channel tile = ONE
+// GroupNorm group (C / G = 8), lane r takes pixel r of the 64-pixel tile -- a lane's eight values are exactly one 16-byte NHWC vector
+// (x, the residual, the destination and the normalised output are each one load / store per lane), and every GroupNorm sum is a sum
+// over the lanes of an image: wave shuffles, no LDS passes, no workgroup barriers.  The LDS epilogues this replaces on these tiles
+// (epilogue_tile_gnf / _gnb: ~12 barriers, two dependent rounds of column sums with 16-way bank conflicts) took 11 000 cycles behind a
+// loop of 11 000 (in-kernel stamps, profiles/r04_small_conv_stamps.txt).  Same arithmetic: statistics in two passes over the
+// bf16-rounded values (forward), the gn_bwd_reg_kernel formulas (backward); sums in a fixed (butterfly) order.
+// Requires C / G == 8 where a GroupNorm is fused, N0 % 8 == 0.  P16: 4x4 maps (an image = 16 lanes), else 8x8 (64 lanes).
+// ----------------------------------------------------------------------------
+template <bool P16>
+__device__ __forceinline__ float img_sum(float v) {                // sum over the lanes of one image, result in every lane of it
+#pragma unroll
+    for (int o = 1; o < (P16 ? 16 : 64); o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <bool P16>
+__device__ __forceinline__ float tile_sum_from_img(float v) {      // image sums -> sum over all 64 pixels of the tile
+    if constexpr (P16) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); }
+    return v;
+}
+__device__ __forceinline__ void unpack8(const float8& a, float (&o)[8]) {
+    o[0] = a.lo.x; o[1] = a.lo.y; o[2] = a.lo.z; o[3] = a.lo.w; o[4] = a.hi.x; o[5] = a.hi.y; o[6] = a.hi.z; o[7] = a.hi.w;
+}
+__device__ __forceinline__ float8 pack8(const float (&o)[8]) {
+    return {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
+}
+__device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+// conv_small_body's parked partials -> pixel r, channels 8g .. 8g+7 of its 64 x 32 tile: two accumulator quads of each of the four
+// k-step partials, added in ascending k (fixed order)
+__device__ __forceinline__ void rows_gather_small(const f32x4* red, const int g, const int r, float (&v)[8]) {
+    const int ph = r >> 5, ti = ((r >> 4) & 1) * 2 + (g >> 1), l0 = (r & 15) + 32 * (g & 1);
+    {
+        const f32x4 a = red[((ph * 4) * 4 + ti) * 64 + l0], b = red[((ph * 4) * 4 + ti) * 64 + l0 + 16];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+        const f32x4 a = red[((ph * 4 + ks) * 4 + ti) * 64 + l0], b = red[((ph * 4 + ks) * 4 + ti) * 64 + l0 + 16];
+        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+}
+template <bool WT, bool P16>
+__device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)[8], const int m0, const int n0, const int g, const int r) {
+    constexpr int P = P16 ? 16 : 64, p_sh = P16 ? 4 : 6;
+    const int64_t m = (int64_t)m0 + r;
+    const int n = n0 + 8 * g, C = d.N;
+    const int img = (m0 >> p_sh) + (P16 ? (r >> 4) : 0);
+    const bool first = (r & (P - 1)) == 0;                          // the lane that writes per-image results
+    const float inv_cnt = 1.f / (8.f * (float)P);
+    if (d.gnb_x) {
+        // ---- GroupNorm backward of the tensor this convolution's input came from (mdm_gemm_can_fuse_gn_bwd: no bias / row / residual)
+        const int G = d.gnb_G;
+        float x[8], ga[8], be[8], gz[8], xh[8], o[8];
+        unpack8(load8(reinterpret_cast<const bf16_t*>(d.gnb_x) + m * C + n), x);
+        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + (n >> 3)) * 2);
+        load8f(d.gnb_gamma + n, ga);
+        load8f(d.gnb_beta + n, be);
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xh[e] = (x[e] - st.x) * st.y;
+            gz[e] = v[e];
+            if (d.gnb_silu) gz[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
+            a1 += gz[e] * ga[e];
+            a2 += gz[e] * ga[e] * xh[e];
+        }
+        a1 = img_sum<P16>(a1);
+        a2 = img_sum<P16>(a2);
+        const float k1 = st.y * a1 * inv_cnt, k2 = st.y * a2 * inv_cnt;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = st.y * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
+        // dgamma / dbeta: sums over every pixel of the tile; lane e adds dgamma[n + e], lane 8 + e dbeta[n + e] (one atomic per
+        // channel per workgroup, as before)
+        float mine = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dg = tile_sum_from_img<P16>(img_sum<P16>(gz[e] * xh[e])), db = tile_sum_from_img<P16>(img_sum<P16>(gz[e]));
+            mine = r == e ? dg : (r == 8 + e ? db : mine);
+        }
+        if (r < 16) atomicAdd((r < 8 ? d.gnb_dgamma : d.gnb_dbeta) + n + (r & 7), mine);
+        if (d.gnb_sum_img || d.gnb_sum_all) {                       // uniform: column sums of dx (before any accumulation)
+            float cs[8], tot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cs[e] = img_sum<P16>(o[e]);
+                const float tt = tile_sum_from_img<P16>(cs[e]);
+                tot = r == e ? tt : tot;
+            }
+            if (d.gnb_sum_img && first) {                           // this workgroup owns (image, channel)
+                float* sp = d.gnb_sum_img + (int64_t)img * d.gnb_sum_ld + n;
+                *reinterpret_cast<float4*>(sp) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                *reinterpret_cast<float4*>(sp + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+            }
+            if (d.gnb_sum_all && r < 8) atomicAdd(d.gnb_sum_all + n + r, tot);
+        }
+        bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n;
+        if (d.acc0) {
+            float old[8];
+            unpack8(load8(p), old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        if (d.gnb_add) {
+            float old[8];
+            unpack8(load8(reinterpret_cast<const bf16_t*>(d.gnb_add) + m * d.ldd0 + n), old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        store8_pub<WT>(p, pack8(o));
+        return;
+    }
+    // ---- forward-type epilogue: scale, bias, time-embedding row, residual, accumulate; optionally the GroupNorm of the result
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+    if (d.bias) {
+        float b[8];
+        load8f(d.bias + n, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    if (d.rowvec) {
+        float b[8];
+        load8f(d.rowvec + (int64_t)div_rows((int)m, d.rows_per_img) * d.rv_ld + n, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    if (d.resid) {
+        float b[8];
+        unpack8(load8(reinterpret_cast<const bf16_t*>(d.resid) + m * d.ldr + n), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    bf16_t* p; int accf;
+    if (n < d.N0) { p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n; accf = d.acc0; }
+    else          { p = reinterpret_cast<bf16_t*>(d.D1) + m * d.ldd1 + (n - d.N0); accf = d.acc1; }
+    if (accf) {
+        float old[8];
+        unpack8(load8(p), old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += old[e];
+    }
+    store8_pub<WT>(p, pack8(v));
+    if (d.gnf_out) {
+        const int G = d.gnf_G;
+        float y[8], ga[8], be[8], o[8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { y[e] = bf2f(f2bf(v[e])); s1 += y[e]; }       // the values as a GroupNorm launch would read them back
+        const float mean = img_sum<P16>(s1) * inv_cnt;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float c0 = y[e] - mean; s2 += c0 * c0; }
+        const float rstd = rsqrtf(img_sum<P16>(s2) * inv_cnt + d.gnf_eps);
+        load8f(d.gnf_gamma + n, ga);
+        load8f(d.gnf_beta + n, be);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = fmaf((y[e] - mean) * rstd, ga[e], be[e]);
+            if (d.gnf_silu) o[e] = silu_f(o[e]);
+        }
+        store8_pub<WT>(reinterpret_cast<bf16_t*>(d.gnf_out) + m * C + n, pack8(o));
+        if (first) {
+            float* sp = d.gnf_stats + ((int64_t)img * G + (n >> 3)) * 2;
+            sp[0] = mean; sp[1] = rstd;
+        }
+    }
+}
+
 #ifdef MDM_STAMP
 // debug build only (make EXTRA=-DMDM_STAMP): cycles per phase of the slab loop, summed over waves
 #define MDM_STAMP_RECS 32768
@@ -1873,6 +2046,8 @@ __device__ __forceinline__ void conv_lin2_body(const mdm_gemm_desc& d, char* rin
         if constexpr (BM == 64 && BN == 64 && WR == 4 && WC == 2 && WK == 1) {
             // 1x1 convolutions on 4x4 / 8x8 maps (the attention block's projections): a 64-row tile is whole images, like the
             // 64-pixel halo tiles -- the same fused GroupNorm epilogues apply (lin2_gn_tile)
+            // (the register form of these epilogues -- epilogue_rows with all eight waves, one GroupNorm group each -- was built for
+            //  these tiles too and measured level: 3.558 vs 3.562 ms/step; not kept)
             if (d.gnb_x) epilogue_tile_gnb<MI, NI, 64, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
             else if (d.gnf_out) epilogue_tile_gnf<MI, NI, 64, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
             else epilogue_tile<BM, BN, NW, MI, NI, bf16_t, WT>(d, ring, m0, n0, wr * WM, wc * WN, lane, t, acc);
@@ -2838,177 +3013,6 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 
 
 // ----------------------------------------------------------------------------
-// epilogue_rows: the epilogue of conv_small_body in REGISTERS.  The waves' partial tiles pass through LDS once anyway (the k-split
-// reduction), so the reader is free to pick its own layout: wave g (of four) takes channels 8g .. 8g+7 of the 32-channel tile = ONE
-// GroupNorm group (C / G = 8), lane r takes pixel r of the 64-pixel tile -- a lane's eight values are exactly one 16-byte NHWC vector
-// (x, the residual, the destination and the normalised output are each one load / store per lane), and every GroupNorm sum is a sum
-// over the lanes of an image: wave shuffles, no LDS passes, no workgroup barriers.  The LDS epilogues this replaces on these tiles
-// (epilogue_tile_gnf / _gnb: ~12 barriers, two dependent rounds of column sums with 16-way bank conflicts) took 11 000 cycles behind a
-// loop of 11 000 (in-kernel stamps, profiles/r04_small_conv_stamps.txt).  Same arithmetic: statistics in two passes over the
-// bf16-rounded values (forward), the gn_bwd_reg_kernel formulas (backward); sums in a fixed (butterfly) order.
-// Requires C / G == 8 where a GroupNorm is fused, N0 % 8 == 0.  P16: 4x4 maps (an image = 16 lanes), else 8x8 (64 lanes).
-// ----------------------------------------------------------------------------
-template <bool P16>
-__device__ __forceinline__ float img_sum(float v) {                // sum over the lanes of one image, result in every lane of it
-#pragma unroll
-    for (int o = 1; o < (P16 ? 16 : 64); o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <bool P16>
-__device__ __forceinline__ float tile_sum_from_img(float v) {      // image sums -> sum over all 64 pixels of the tile
-    if constexpr (P16) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); }
-    return v;
-}
-__device__ __forceinline__ void unpack8(const float8& a, float (&o)[8]) {
-    o[0] = a.lo.x; o[1] = a.lo.y; o[2] = a.lo.z; o[3] = a.lo.w; o[4] = a.hi.x; o[5] = a.hi.y; o[6] = a.hi.z; o[7] = a.hi.w;
-}
-__device__ __forceinline__ float8 pack8(const float (&o)[8]) {
-    return {make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7])};
-}
-__device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
-template <bool WT, bool P16>
-__device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, const f32x4* red, const int m0, const int n0, const int g, const int r) {
-    constexpr int P = P16 ? 16 : 64, p_sh = P16 ? 4 : 6;
-    // pixel r, channels 8g .. 8g+7 of the tile: two accumulator quads of each of the four k-step partials (ascending k: fixed order)
-    const int ph = r >> 5, ti = ((r >> 4) & 1) * 2 + (g >> 1), l0 = (r & 15) + 32 * (g & 1);
-    float v[8];
-    {
-        const f32x4 a = red[((ph * 4) * 4 + ti) * 64 + l0], b = red[((ph * 4) * 4 + ti) * 64 + l0 + 16];
-        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    }
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) {
-        const f32x4 a = red[((ph * 4 + ks) * 4 + ti) * 64 + l0], b = red[((ph * 4 + ks) * 4 + ti) * 64 + l0 + 16];
-        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
-    }
-    const int64_t m = (int64_t)m0 + r;
-    const int n = n0 + 8 * g, C = d.N;
-    const int img = (m0 >> p_sh) + (P16 ? (r >> 4) : 0);
-    const bool first = (r & (P - 1)) == 0;                          // the lane that writes per-image results
-    const float inv_cnt = 1.f / (8.f * (float)P);
-    if (d.gnb_x) {
-        // ---- GroupNorm backward of the tensor this convolution's input came from (mdm_gemm_can_fuse_gn_bwd: no bias / row / residual)
-        const int G = d.gnb_G;
-        float x[8], ga[8], be[8], gz[8], xh[8], o[8];
-        unpack8(load8(reinterpret_cast<const bf16_t*>(d.gnb_x) + m * C + n), x);
-        const float2 st = *reinterpret_cast<const float2*>(d.gnb_stats + ((int64_t)img * G + (n >> 3)) * 2);
-        load8f(d.gnb_gamma + n, ga);
-        load8f(d.gnb_beta + n, be);
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            xh[e] = (x[e] - st.x) * st.y;
-            gz[e] = v[e];
-            if (d.gnb_silu) gz[e] *= silu_grad_f(fmaf(xh[e], ga[e], be[e]));
-            a1 += gz[e] * ga[e];
-            a2 += gz[e] * ga[e] * xh[e];
-        }
-        a1 = img_sum<P16>(a1);
-        a2 = img_sum<P16>(a2);
-        const float k1 = st.y * a1 * inv_cnt, k2 = st.y * a2 * inv_cnt;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = st.y * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
-        // dgamma / dbeta: sums over every pixel of the tile; lane e adds dgamma[n + e], lane 8 + e dbeta[n + e] (one atomic per
-        // channel per workgroup, as before)
-        float mine = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float dg = tile_sum_from_img<P16>(img_sum<P16>(gz[e] * xh[e])), db = tile_sum_from_img<P16>(img_sum<P16>(gz[e]));
-            mine = r == e ? dg : (r == 8 + e ? db : mine);
-        }
-        if (r < 16) atomicAdd((r < 8 ? d.gnb_dgamma : d.gnb_dbeta) + n + (r & 7), mine);
-        if (d.gnb_sum_img || d.gnb_sum_all) {                       // uniform: column sums of dx (before any accumulation)
-            float cs[8], tot = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                cs[e] = img_sum<P16>(o[e]);
-                const float tt = tile_sum_from_img<P16>(cs[e]);
-                tot = r == e ? tt : tot;
-            }
-            if (d.gnb_sum_img && first) {                           // this workgroup owns (image, channel)
-                float* sp = d.gnb_sum_img + (int64_t)img * d.gnb_sum_ld + n;
-                *reinterpret_cast<float4*>(sp) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-                *reinterpret_cast<float4*>(sp + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
-            }
-            if (d.gnb_sum_all && r < 8) atomicAdd(d.gnb_sum_all + n + r, tot);
-        }
-        bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n;
-        if (d.acc0) {
-            float old[8];
-            unpack8(load8(p), old);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += old[e];
-        }
-        if (d.gnb_add) {
-            float old[8];
-            unpack8(load8(reinterpret_cast<const bf16_t*>(d.gnb_add) + m * d.ldd0 + n), old);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += old[e];
-        }
-        store8_pub<WT>(p, pack8(o));
-        return;
-    }
-    // ---- forward-type epilogue: scale, bias, time-embedding row, residual, accumulate; optionally the GroupNorm of the result
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
-    if (d.bias) {
-        float b[8];
-        load8f(d.bias + n, b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b[e];
-    }
-    if (d.rowvec) {
-        float b[8];
-        load8f(d.rowvec + (int64_t)div_rows((int)m, d.rows_per_img) * d.rv_ld + n, b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b[e];
-    }
-    if (d.resid) {
-        float b[8];
-        unpack8(load8(reinterpret_cast<const bf16_t*>(d.resid) + m * d.ldr + n), b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b[e];
-    }
-    bf16_t* p; int accf;
-    if (n < d.N0) { p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n; accf = d.acc0; }
-    else          { p = reinterpret_cast<bf16_t*>(d.D1) + m * d.ldd1 + (n - d.N0); accf = d.acc1; }
-    if (accf) {
-        float old[8];
-        unpack8(load8(p), old);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += old[e];
-    }
-    store8_pub<WT>(p, pack8(v));
-    if (d.gnf_out) {
-        const int G = d.gnf_G;
-        float y[8], ga[8], be[8], o[8];
-        float s1 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { y[e] = bf2f(f2bf(v[e])); s1 += y[e]; }       // the values as a GroupNorm launch would read them back
-        const float mean = img_sum<P16>(s1) * inv_cnt;
-        float s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float c0 = y[e] - mean; s2 += c0 * c0; }
-        const float rstd = rsqrtf(img_sum<P16>(s2) * inv_cnt + d.gnf_eps);
-        load8f(d.gnf_gamma + n, ga);
-        load8f(d.gnf_beta + n, be);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o[e] = fmaf((y[e] - mean) * rstd, ga[e], be[e]);
-            if (d.gnf_silu) o[e] = silu_f(o[e]);
-        }
-        store8_pub<WT>(reinterpret_cast<bf16_t*>(d.gnf_out) + m * C + n, pack8(o));
-        if (first) {
-            float* sp = d.gnf_stats + ((int64_t)img * G + (n >> 3)) * 2;
-            sp[0] = mean; sp[1] = rstd;
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------
 // conv_small: the 3x3 stride-1 "same" convolutions of the 4x4 / 8x8 maps (forward incl. the folded x2 upsample, and the data gradient
 // through the transposed shadow) with the REDUCTION split over the waves.  On conv_halo_body's 64 x 32 tiles of these maps every wave
 // owns ONE 16 x 16 accumulator: per filter tap it reads four fragments for two MFMAs that wait for each other, and the in-kernel
@@ -3168,8 +3172,10 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
         const int cpg = d.gnb_x ? d.N / d.gnb_G : (d.gnf_out ? d.N / d.gnf_G : 8);
         if (MDM_SMALL_EPI && cpg == 8 && (d.N0 & 7) == 0) {                                                         // uniform
             if (wave < 4) {
-                if (p_sh == 4) epilogue_rows<WT, true>(d, red, m0, n0, wave, lane);
-                else epilogue_rows<WT, false>(d, red, m0, n0, wave, lane);
+                float v8[8];
+                rows_gather_small(red, wave, lane, v8);
+                if (p_sh == 4) epilogue_rows<WT, true>(d, v8, m0, n0, wave, lane);
+                else epilogue_rows<WT, false>(d, v8, m0, n0, wave, lane);
             }
         } else {
         const int wr = wave >> 1, wc = wave & 1;
