@@ -273,7 +273,7 @@ def bench_cut_graph(mdm, TrainStep, model, sched, args, optim, ema, used, opt_, 
             "graphs_per_step": pieces + 2, "note": "front / bucket pieces / tail hipGraphs over 32 MB weight-gradient groups, bucket hooks with world = 1 (no exchange); the one-graph form runs one group"}
 
 
-def bench_config(mdm, _lib, TrainStep, name, dev, opt_):
+def bench_config(mdm, _lib, TrainStep, name, dev, opt_, full=True):
     """One of BASELINE.json's other configurations on this GPU: step time, family TFLOP/s; cfg5: the 250-step sampler."""
     from mdm.unet import unet6_config
     dt = mdm.BF16
@@ -310,7 +310,7 @@ def bench_config(mdm, _lib, TrainStep, name, dev, opt_):
     if name == "cfg5":
         a.sample_num = 100
         # "f32_split" = the sampler of record (fp32 storage, convolution products as bf16 hi / lo pairs): the model's own sampling plan
-        for tag in ("bf16", "f32_split", "f32"):
+        for tag in (("bf16", "f32_split", "f32") if full else ("bf16", "f32_split")):
             net = (model.with_batch(100) if tag == "bf16" else model.sampling_plan(100, tag)).eval()
             smp = mdm.Sampler(None, a, sched, [None] * 3)
             smp.sample(net, used[:3])
@@ -336,7 +336,13 @@ def main():
     ap.add_argument("--sampler-steps", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-timed replay (kernel-count profiles: every profiled launch then belongs to a whole step)")
-    ap.add_argument("--wgrad-group-mb", type=float, default=None, help=argparse.SUPPRESS)      # experiments only
+    ap.add_argument("--wgrad-group-mb", type=float, default=None,
+                    help="size of a weight-gradient group = launch = gradient bucket unit (default: one group on one GPU, 32 MB under data parallelism)")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size of the all-reduce (N > 1; default 32)")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="N > 1: build the persistent weight-gradient launch for CUs - R workgroups so that RCCL's kernels find free CUs beside it")
+    ap.add_argument("--windows", type=int, default=4, help="further timed windows of --steps steps behind the headline one (spread: min / median / max)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cfg3 / cfg4 / cfg5 legs of the default run")
     ap.add_argument("--config", action="append", default=[], choices=["cfg3", "cfg4", "cfg5"],
                     help="also measure this BASELINE.json configuration (reported under `extras`; the headline stays cfg2)")
     ap.add_argument("--cut-graph", action="store_true", help="also time the data-parallel (cut) form of the step graph on this one GPU")
@@ -387,6 +393,8 @@ def main():
 
     cfg = mdm.unet6_config(32)
     xk = {}
+    if opt_.reserve_cus > 0:
+        os.environ["MDM_WGRAD_RESERVE_CUS"] = str(opt_.reserve_cus)       # read by mdm_wgrad_group_create
     if opt_.wgrad_group_mb is not None:
         xk["wgrad_group_bytes"] = int(opt_.wgrad_group_mb * (1 << 20))
     if opt_.no_pair:
@@ -397,8 +405,10 @@ def main():
     sched = mdm.Scheduler(args, device=dev)
     sched.update_ddpm_num_steps(1000)
     used = sched.get_timesteps_epoch(0, 1)
-    comm = GradComm(wire=opt_.grad_wire, always_exchange=rehearse) if (world > 1 or rehearse) else None
+    ck = {} if opt_.bucket_mb is None else {"bucket_bytes": int(opt_.bucket_mb * (1 << 20))}
+    comm = GradComm(wire=opt_.grad_wire, always_exchange=rehearse, **ck) if (world > 1 or rehearse) else None
     step = TrainStep(model, sched, args, optim, ema, mean_shift=True, comm=comm)
+    step.time_comm = comm is not None
     g = torch.Generator().manual_seed(100 + rank)
     step.x0.copy_(torch.rand(N, 3, 32, 32, generator=g) * 2 - 1)          # synthetic batch, resident in HBM
 
@@ -415,6 +425,7 @@ def main():
             torch.cuda.synchronize()
             log("first step done (graphs captured)")
     barrier()
+    step.comm_events = []            # the exposed-wait samples of the warm-up steps do not count
     log("warm-up done")
     t0 = time.perf_counter()
     for _ in range(opt_.steps):
@@ -429,6 +440,26 @@ def main():
     log(f"timed region: {elapsed:.3f}s for {opt_.steps} steps, loss {loss:.5f}")
     ms_per_step = 1e3 * elapsed / opt_.steps
     value = N * world * opt_.steps / elapsed
+    comm_rep = step.comm_report() if comm is not None else None          # exposed wait of the headline region's steps
+    # ---- spread: the same K steps again, `--windows` times, each bracketed like the headline region (which stays the `value`)
+    wins = [ms_per_step]
+    for _ in range(max(0, opt_.windows)):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(opt_.steps):
+            step.run_device(None, used)
+        barrier()
+        el = time.perf_counter() - t1
+        if world > 1 or rehearse:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el = float(tt)
+        wins.append(1e3 * el / opt_.steps)
+    step.comm_events = []
+    ws = sorted(wins)
+    windows = {"n": len(wins), "steps_each": opt_.steps, "ms_per_step_min": round(ws[0], 4), "ms_per_step_median": round(ws[len(ws) // 2], 4),
+               "ms_per_step_max": round(ws[-1], 4), "note": "window 0 is the headline region (`value`, `ms_per_step`)"}
+    log(f"windows: {[round(w, 4) for w in wins]}")
 
     # ---- roofline of the contraction kernel family: HIP events around every launch, on the launch stream
     roofline = None
@@ -464,16 +495,19 @@ def main():
         # HBM bytes per launch of this kernel family from PMC counters: collected out of band by
         # scripts/pmc_traffic.sh (rocprofv3 cannot run inside the timed process) and committed under profiles/
         traffic = mfma_busy = pmc_src = None
-        for fn in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+        pmc_head = mfma_cal = None
+        for fn in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as fh:
                     pj = json.load(fh)
                 traffic, mfma_busy, pmc_src = round(pj["hbm_bytes_per_launch"]), pj.get("mfma_busy"), "profiles/" + fn
+                pmc_head, mfma_cal = pj.get("git_head"), pj.get("mfma_busy_calibration")
                 break
             except Exception:
                 pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "mfma_busy": mfma_busy, "pmc_source": pmc_src,
+                    "pmc_head": pmc_head, "mfma_busy_calibration": mfma_cal,
                     "launches_per_step": n_launch // reps, "flops_per_step": tot_fl / reps,
                     "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "kernel_ms_per_step": round(tot_ms / reps, 3),
                     "event_pair_us": round(1e3 * pair_ms, 2)}
@@ -546,6 +580,23 @@ def main():
             log(f"sampler {tag}: {sec:.2f}s")
             sampler[tag] = {"dtype": tag, "arithmetic": SAMPLER_MODES[tag], "steps": nst, "sample_num": args.sample_num, "seconds": round(sec, 3),
                             "ms_per_step": round(1e3 * sec / nst, 3), "finite": bool(torch.isfinite(x0_hat).all())}
+            # roofline of the reverse step: algorithmic FLOPs of ONE U-Net forward at sample_num images (the launch list's own
+            # bookkeeping: 2 N OH OW Cout Cin taps per convolution, 2 M N K per contraction) over the measured wall clock per step.
+            # Ceilings: dense bf16 MFMA 2 500 TFLOP/s; split products issue three bf16 MFMAs per product -> 833; exact fp32 MFMA 157.3
+            fl_step = float(sum(f for f, _ in net.forward_plan.flops.values()))
+            ceil = {"f32": 157.3, "f32_split": PEAK_BF16_TFLOPS / 3.0, "bf16": PEAK_BF16_TFLOPS}[tag]
+            tfs = fl_step * nst / sec / 1e12
+            rf = {"bound": "mfma", "flops_per_step": fl_step, "achieved": round(tfs, 1), "unit": "TFLOP/s", "peak": round(ceil, 1),
+                  "frac": round(tfs / ceil, 4), "frac_of_bf16_peak": round(tfs / PEAK_BF16_TFLOPS, 4),
+                  "launches_per_step": len(net.forward_plan.calls)}
+            try:        # the dominant kernel of this mode from the committed kernel trace (scripts/prof_sampler_mode.sh)
+                with open(os.path.join(ROOT, "profiles", "r04_sampler_roofline.json")) as fh:
+                    dk = json.load(fh).get(tag)
+                if dk:
+                    rf["dominant_kernel"] = dk
+            except Exception:
+                pass
+            sampler[tag]["roofline"] = rf
             del net
             par = None
             if ref is not None:
@@ -571,9 +622,15 @@ def main():
     if rank == 0 and world == 1 and opt_.cut_graph:
         extras["cut_graph"] = bench_cut_graph(mdm, TrainStep, model, sched, args, optim, ema, used, opt_, ms_per_step)
     if rank == 0 and world == 1:
-        for name in opt_.config:
+        # the other BASELINE configurations ride in the DEFAULT line (a few seconds each) so that the driver times them too;
+        # `--config` asks for one explicitly (cfg5 then also runs the exact-fp32 250-step sampler), `--no-extras` skips them
+        names = list(opt_.config) if opt_.config else ([] if (opt_.no_extras or opt_.no_sampler) else ["cfg3", "cfg4", "cfg5"])
+        for name in names:
             log(f"extra configuration {name}")
-            extras[name] = bench_config(mdm, _lib, TrainStep, name, dev, opt_)
+            try:
+                extras[name] = bench_config(mdm, _lib, TrainStep, name, dev, opt_, full=bool(opt_.config))
+            except Exception as e:      # noqa: BLE001 -- an extra must never take the headline line down
+                extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         out = {
@@ -586,8 +643,10 @@ def main():
                                    "AdamW lr 1e-4 + clip 1.0 + EMA, device Philox RNG, hipGraph replay",
                        "global_batch": N * world, "per_gpu_batch": N, "image": "3x32x32",
                        "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
-            "roofline": roofline, "step_hbm": step_hbm, "cpu_baseline": cpu, "sampler": sampler,
+            "roofline": roofline, "step_hbm": step_hbm, "cpu_baseline": cpu, "sampler": sampler, "windows": windows,
         }
+        if comm_rep is not None:
+            out["comm"] = comm_rep
         if extras:
             out["extras"] = extras
         print(json.dumps(out))

@@ -4517,7 +4517,7 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
         if (tab.n > 0) { tab.first_block[tab.n] = blocks; g->reduces.push_back(tab); g->reduce_blocks.push_back(blocks); }
         tab.n = 0; blocks = 0;
     };
-    static const int n_cu = [] {
+    static const int n_cu_dev = [] {
         int dev = 0; hipDeviceProp_t pr;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
         return pr.multiProcessorCount;
@@ -4528,6 +4528,10 @@ extern "C" int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, vo
     // CU) and the 8x8 maps' (10 per CU) came out 10-40 % slower.  So: only where a CU's share is long.
     const char* ms_env = getenv("MDM_TAPS_MIN_SHARE");          // (read per group: the kernel test forces the path on a small group)
     const int min_share = ms_env ? atoi(ms_env) : 48;
+    // MDM_WGRAD_RESERVE_CUS=r (data-parallel runs): the persistent nine-tap launch is built for CUs - r workgroups, leaving r CUs
+    // to whatever else wants to run beside it -- RCCL's all-reduce kernels of the previous bucket (bench.py --reserve-cus)
+    const char* rs_env = getenv("MDM_WGRAD_RESERVE_CUS");
+    const int n_cu = std::max(8, n_cu_dev - (rs_env ? std::max(0, atoi(rs_env)) : 0));
     long long taps_slabs = 0;
     for (int i = 0; i < n; ++i) {
         Resolved r;

@@ -80,6 +80,8 @@ class TrainStep:
         self._used_key = None
         self._graphs = None
         self.use_graph = getattr(args, "use_graph", True)
+        self.time_comm = False                # bench.py: record HIP events around the exposed wait for the gradient exchange
+        self.comm_events = []
         self.force_cut = bool(getattr(args, "cut_step_graph", False))    # single GPU: run the data-parallel (cut) form of the step
 
     # ---- pieces shared by both modes -------------------------------------------------------
@@ -291,6 +293,32 @@ class TrainStep:
         if rest is not None:
             go(rest)
         if self.comm is not None:
-            self.comm.wait_all(G)
+            if self.time_comm:
+                # what the compute stream WAITS for the exchange behind the last backward piece (the part of the all-reduce that
+                # the backward did not hide): HIP events on the compute stream around the stream-level waits
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.comm.wait_all(G)
+                e1.record()
+                self.comm_events.append((e0, e1))
+            else:
+                self.comm.wait_all(G)
         go(tail)
         return self.loss
+
+    def comm_report(self):
+        """dict for bench.py's `comm` object: bytes on the wire per step, bucket plan, and -- when `time_comm` was set -- the
+        exposed wait per step (median / max over the recorded steps; synchronises)."""
+        c, m = self.comm, self.model
+        if c is None:
+            return None
+        out = {"world": c.world, "wire": c.wire, "bytes_per_step": int(m.store.size * (2 if c.wire == "bf16" else 4)),
+               "buckets": len(c.buckets), "bucket_bytes": int(c.bucket_bytes), "tail_bytes": int(c.tail_bytes),
+               "bucket_sizes_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi in c.buckets],
+               "wgrad_groups": len(m.wgrad_groups), "wgrad_group_bytes": int(min(m.wgrad_group_bytes, m.store.size * 4))}
+        if self.comm_events:
+            torch.cuda.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in self.comm_events)
+            out.update(exposed_ms=round(ms[len(ms) // 2], 4), exposed_ms_max=round(ms[-1], 4), exposed_samples=len(ms))
+            self.comm_events = []
+        return out

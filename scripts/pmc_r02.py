@@ -12,7 +12,8 @@ def rows(kind):
 
 
 def family(k):
-    if any(x in k for x in ("conv_halo", "conv_lin2", "conv_pair", "wgrad_group", "wgrad_taps", "tile_parts_reduce", "wgrad_lin", "gemm_ring", "gemm_bf16", "splitk_")):
+    if any(x in k for x in ("conv_halo", "conv_small", "conv_lin2", "conv_pair", "conv_thin", "chain_kernel", "wgrad_group", "wgrad_taps", "tile_parts_reduce",
+                            "wgrad_lin", "gemm_ring", "gemm_bf16", "splitk_")):
         return "contraction"
     if "attn_" in k: return "attention"
     if "gn_" in k: return "groupnorm"
@@ -63,5 +64,20 @@ res["launches_per_step"] = calls
 res["hbm_bytes_per_launch"] = con["hbm_bytes_per_step"] / calls
 res["mfma_busy"] = con.get("mfma_busy")
 res["steps_counted"] = [nf, nw, nq, nc]
+res["git_head"] = os.environ.get("GIT_HEAD")
+# Calibration (scripts/pmc_r04.sh): the same counter and formula on scripts/micro/mfma_rate.hip, whose waves issue v_mfma_f32_16x16x32_bf16
+# back to back (16.4 cycles per MFMA per SIMD by s_memtime, 2 130 TFLOP/s: the pipe IS busy every cycle).  What the formula reads there
+# is the counter's value for "100 % busy"; family busy / that value = share of the matrix pipe's issue slots in use.
+try:
+    cal = rows("cal")
+    a = collections.defaultdict(float)
+    for r in cal:
+        a[r["Counter_Name"]] += float(r["Counter_Value"])
+    full = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
+    res["mfma_busy_calibration"] = {"busy_reading_of_a_full_rate_mfma_loop": full, "family_busy_calibrated": (con.get("mfma_busy") or 0.0) / full,
+                                    "source": "scripts/micro/mfma_rate.hip under the same counter / formula",
+                                    "micro_output": open(f"{out}/cal.txt").read().strip().splitlines()[-2:]}
+except Exception as e:      # noqa: BLE001
+    res["mfma_busy_calibration"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 json.dump(res, open(f"{out}/pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -195,10 +195,17 @@ def test_bench_gpus_2_prints_a_two_rank_line():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8",
-                        "--no-cpu-baseline", "--no-sampler"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-sampler", "--windows", "1", "--bucket-mb", "32", "--reserve-cus", "8"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # the line explains its own communication: bytes on the wire, bucket plan, the exposed wait behind the last backward piece
+    c = out["comm"]
+    assert c["world"] == 2 and c["wire"] == "f32" and 140e6 < c["bytes_per_step"] < 150e6, c
+    assert c["buckets"] >= 3 and c["buckets"] == len(c["bucket_sizes_mb"]) and c["wgrad_groups"] >= 3, c
+    assert c["exposed_samples"] == 3 and 0.0 <= c["exposed_ms"] <= c["exposed_ms_max"], c
+    w = out["windows"]
+    assert w["n"] == 2 and w["ms_per_step_min"] <= w["ms_per_step_median"] <= w["ms_per_step_max"], w

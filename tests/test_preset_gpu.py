@@ -46,6 +46,8 @@ def _check_grads(grads, want, tol_g, tag):
     keys = [k for k in want if float(want[k].norm()) > 1e-2 * med]
     assert len(keys) > 0.9 * len(want), len(keys)
     worst = max((_rel(grads[k], want[k]), k) for k in keys)
+    from _notes import note
+    note("preset_gradients", dict(case=tag, rel_l2_all=_rel(a, b), worst_tensor_rel=worst[0], worst_tensor=worst[1]))
     assert worst[0] < 2 * tol_g, (tag, worst)
 
 
@@ -77,6 +79,8 @@ def test_preset_forward_and_all_gradients_eager_and_graph(n, dt, tol_y, tol_g):
     torch.cuda.synchronize()
     y_e, g_e = read_y(), net.store.grad_dict()
     assert _rel(y_e, yo) < tol_y, _rel(y_e, yo)
+    from _notes import note
+    note("preset_forward", dict(n=n, dtype=dt, rel_l2_y=_rel(y_e, yo)))
     _check_grads(g_e, want, tol_g, f"eager n={n} dt={dt}")
 
     # ---- the same two plans as ONE captured hipGraph, replayed twice (second replay = what bench.py times)
