@@ -3658,7 +3658,7 @@ static bool wgrad_taps_eligible(const mdm_gemm_desc& d) {
     static const bool off = [] { const char* e = getenv("MDM_WGRAD_TAPS"); return e && atoi(e) == 0; }();
     if (off) return false;
     return d.dtype == MDM_BF16 && d.layout == 2 && d.conv && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 &&
-           (d.OW == 8 || d.OW == 16 || d.OW == 32) && d.OH >= 2 && (d.OH & (d.OH - 1)) == 0 && d.OH * d.OW >= 64 && d.IH == d.OH && d.IW == d.OW &&
+           (d.OW == 8 || d.OW == 16 || d.OW == 32 || d.OW == 64) && d.OH >= 2 && (d.OH & (d.OH - 1)) == 0 && d.OH * d.OW >= 64 && d.IH == d.OH && d.IW == d.OW &&
            (d.ups == 0 || d.ups == 1) && (d.M % TAPS_BM == 0 || (d.M < TAPS_BM && d.M % 8 == 0)) && (d.N % TAPS_BN == 0 || (d.N < TAPS_BN && d.N % 8 == 0)) &&
            cdiv(d.N, TAPS_BN) * cdiv(d.M, TAPS_BM) <= 4095 && d.K % 64 == 0 &&
            d.K / 64 < 65535 && d.C0 % 8 == 0 && d.C1 % 8 == 0 && d.N == d.C0 + d.C1 && d.out_f32 && !d.acc0 && d.ldd0 == d.N && d.N0 == d.N &&

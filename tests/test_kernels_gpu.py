@@ -696,6 +696,7 @@ def test_grouped_weight_gradients_match_self_contained_ones():
               # two output-channel tiles, tiles cut over several CUs (partial slots + tile_parts_reduce_kernel)
               (4, 8, 64, 64, 128, 1, 0), (4, 16, 64, 64, 128, 1, 0), (2, 16, 128, 0, 128, 1, 1), (4, 4, 64, 0, 128, 1, 1),
               (2, 32, 64, 0, 256, 1, 0),
+              (1, 64, 64, 64, 128, 1, 0), (2, 64, 128, 0, 128, 1, 0),    # 64-wide maps (cfg3): a 64-pixel slab is ONE image row; concat
               (4, 16, 8, 0, 128, 1, 0), (4, 16, 128, 0, 8, 1, 0)]          # the 8-channel ends of the net: one partly filled tile
     jobs = []
     for rep in range(240):
