@@ -174,6 +174,150 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ forward, K / V by LDS-DMA
+// L >= 256 (cfg4: L = 1024, cfg3: L = 256): attn_fwd_kernel stages every 64-key tile through registers between two barriers --
+// load, store, barrier, multiply -- and ran at 170 TFLOP/s at L = 1024 (8.6 GFLOP in 50 us; profiles/r03_cfg4_kernel_stats.csv):
+// 16 dependent round trips to L2 per workgroup.  Here the K and V tiles of key tile j+1 (j+2 where three stages fit: D <= 128)
+// arrive by LDS-DMA (global_load_lds_dwordx4) while tile j multiplies; counted vmcnt, one barrier per tile.  Same tile layout
+// (tile_off: the DMA's per-lane SOURCE address carries the swizzle), same arithmetic, same orientation as attn_fwd_kernel; the
+// transposing V reads go through inline asm (the builtin form makes hipcc drain every DMA in flight, gemm.hip finding 32).
+// Requires L % 64 == 0.
+__device__ __forceinline__ void attn_dma16(const void* src, char* lds_piece_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_piece_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef unsigned av2u_t __attribute__((ext_vector_type(2)));
+typedef unsigned av4u_t __attribute__((ext_vector_type(4)));
+struct ATrFrag { av2u_t lo, hi; };
+template <int D>
+__device__ __forceinline__ void frag_tr_issue(const char* tile, int s, int d0, int lane, ATrFrag& f) {    // frag_tr's two reads, not waited for
+    const int i = lane & 15, g = lane >> 4;
+    const int q = i >> 2, p = i & 3;
+    const int r0 = 32 * s + 4 * g + q, r1 = r0 + 16;
+    const int chunk = (d0 >> 3) + (p >> 1), sub = (p & 1) * 8;
+    const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tile + tile_off<D>(r0, chunk) + sub);
+    const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tile + tile_off<D>(r1, chunk) + sub);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1) : "memory");
+}
+__device__ __forceinline__ bf16x8 atr_value(const ATrFrag& f) {
+    const av4u_t v = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_dma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
+                                                           int L, float scale) {
+    constexpr int KS = D / 32, DB = D / 16, TILE = 64 * 2 * D, NST = D <= 128 ? 3 : 2;
+    constexpr int PPT = TILE / 1024, PW = PPT / 4;                 // 1-KiB pieces per K (or V) tile; per wave
+    constexpr int CPR = D / 8, RPP = 1024 / (2 * D);               // 16-byte chunks per tile row; tile rows per piece
+    constexpr int PPR = D / 16, MASK = (PPR - 1) < 7 ? (PPR - 1) : 7;
+    static_assert(PW >= 1 && RPP >= 1, "attn_fwd_dma: D in {64, 128, 256}");
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * D;
+    const bf16_t* base = qkv + (int64_t)n * L * ld;
+    const int qrow = q0 + (lane & 15);                             // < L: L % 64 == 0
+    const int ntiles = L >> 6;
+    // this lane's slot in each of its pieces: tile row, and which source chunk the tile layout wants there
+    int64_t src_off[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        const int row = (wave * PW + k) * RPP + lane / CPR, pos = lane % CPR;
+        const int c = (((pos >> 1) ^ (row & MASK)) << 1) | (pos & 1);
+        src_off[k] = ((int64_t)row * ld + c * 8) * 2;
+    }
+    const char* const kbase = reinterpret_cast<const char*>(base + D);
+    auto issue_tile = [&](int j, int stage) {
+        const int jt = j < ntiles ? j : ntiles - 1;                // (beyond the end: the last tile again, into a stage nobody reads)
+        const char* src = kbase + (int64_t)jt * 64 * ld * 2;
+        char* dst = lds + stage * 2 * TILE + wave * PW * 1024;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) attn_dma16(src + src_off[k], dst + k * 1024);
+#pragma unroll
+        for (int k = 0; k < PW; ++k) attn_dma16(src + src_off[k] + D * 2, dst + TILE + k * 1024);
+    };
+    issue_tile(0, 0);
+    if (NST == 3) issue_tile(1, 1);
+    bf16x8 Qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) Qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qrow * ld + ks * 32 + 8 * g);
+    f32x4 O[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) O[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, lsum = 0.f;
+    int stage = 0;
+    for (int j = 0; j < ntiles; ++j) {
+        if (NST == 3) attn_wait_vmcnt<2 * PW>(); else attn_wait_vmcnt<0>();       // tile j of this wave has landed (tile j+1 may be in flight)
+        __builtin_amdgcn_s_barrier();                              // ... of every wave; and everybody is done with tile j-1
+        const int ns = stage + NST - 1 >= NST ? stage - 1 : stage + NST - 1;
+        issue_tile(j + NST - 1, ns);
+        const char* Kt = lds + stage * 2 * TILE;
+        const char* Vt = Kt + TILE;
+        f32x4 s[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            s[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Kt, 16 * jb, ks, lane), Qf[ks], s[jb], 0, 0, 0);
+        }
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[jb][r] *= scale;
+                tmax = fmaxf(tmax, s[jb][r]);
+            }
+        tmax = group_max(tmax);
+        const float m_new = fmaxf(m, tmax), alpha = __expf(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(s[jb][r] - m_new);
+                s[jb][r] = pv;
+                rs += pv;
+            }
+        rs = group_sum(rs);
+        lsum = lsum * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) { O[db][0] *= alpha; O[db][1] *= alpha; O[db][2] *= alpha; O[db][3] *= alpha; }
+        const bf16x8 pf0 = pack_pair(s[0], s[1]), pf1 = pack_pair(s[2], s[3]);
+        constexpr int CH = DB < 4 ? DB : 4;                        // V fragments of four 16-channel blocks in flight at a time
+#pragma unroll
+        for (int d0 = 0; d0 < DB; d0 += CH) {
+            ATrFrag vf[CH][2];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { frag_tr_issue<D>(Vt, 0, 16 * (d0 + c), lane, vf[c][0]); frag_tr_issue<D>(Vt, 1, 16 * (d0 + c), lane, vf[c][1]); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                O[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(vf[c][0]), pf0, O[d0 + c], 0, 0, 0);
+                O[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(vf[c][1]), pf1, O[d0 + c], 0, 0, 0);
+            }
+        }
+        stage = stage + 1 == NST ? 0 : stage + 1;
+    }
+    attn_wait_vmcnt<0>();
+    const float inv = 1.f / lsum;
+    bf16_t* orow = o + ((int64_t)n * L + qrow) * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        f32x4 v = O[db];
+        v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+        store4bf(orow + 16 * db + 4 * g, v);
+    }
+    if (g == 0) lse[(int64_t)n * L + qrow] = m + __logf(lsum);
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dQ (and delta)
 template <int D>
 __device__ __forceinline__ void attn_bwd_dq_body(char* lds, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
@@ -338,6 +482,243 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* lds, const bf16_t* __res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward, tiles by LDS-DMA
+// The two backward bodies with their 64-row tiles (K and V for dQ; Q and dO for dK / dV) prefetched by LDS-DMA like
+// attn_fwd_dma_kernel: same tile layout, arithmetic and orientation as attn_bwd_dq_body / attn_bwd_dkv_body.  L % 64 == 0.
+template <int D>
+struct AttnPipe {              // two operand tiles per step, NST stages; every wave issues 2 * PW pieces per step
+    static constexpr int TILE = 64 * 2 * D, NST = D <= 128 ? 3 : 2, PPT = TILE / 1024, PW = PPT / 4;
+    static constexpr int CPR = D / 8, RPP = 1024 / (2 * D), PPR = D / 16, MASK = (PPR - 1) < 7 ? (PPR - 1) : 7;
+    int64_t off_a[PW], off_b[PW];
+    const char *src_a, *src_b;
+    int64_t step_a, step_b;
+    int wave, ntiles;
+    __device__ __forceinline__ void init(int lane, int wave_, const void* a, int ld_a, const void* b, int ld_b, int ntiles_) {
+        wave = wave_; ntiles = ntiles_;
+        src_a = reinterpret_cast<const char*>(a); src_b = reinterpret_cast<const char*>(b);
+        step_a = (int64_t)64 * ld_a * 2; step_b = (int64_t)64 * ld_b * 2;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int row = (wave * PW + k) * RPP + lane / CPR, pos = lane % CPR;
+            const int c = (((pos >> 1) ^ (row & MASK)) << 1) | (pos & 1);
+            off_a[k] = ((int64_t)row * ld_a + c * 8) * 2;
+            off_b[k] = ((int64_t)row * ld_b + c * 8) * 2;
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds, int j, int stage) const {
+        const int jt = j < ntiles ? j : ntiles - 1;
+        char* dst = lds + stage * 2 * TILE + wave * PW * 1024;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) attn_dma16(src_a + jt * step_a + off_a[k], dst + k * 1024);
+#pragma unroll
+        for (int k = 0; k < PW; ++k) attn_dma16(src_b + jt * step_b + off_b[k], dst + TILE + k * 1024);
+    }
+    // top of step j: this wave's tiles j have landed (NST == 3: those of j+1 may fly), every wave is done with j-1, then prefetch
+    __device__ __forceinline__ void step(char* lds, int j, int& stage_next) const {
+        if (NST == 3) attn_wait_vmcnt<2 * PW>(); else attn_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        issue(lds, j + NST - 1, stage_next);
+    }
+};
+template <int D, int NF>       // NF transposed fragments of `tile` (k-step s, 16-row blocks d0 ..) -> registers, waited for
+__device__ __forceinline__ void frag_tr_burst(const char* tile, int db0, int lane, ATrFrag (&f)[NF][2]) {
+#pragma unroll
+    for (int c = 0; c < NF; ++c) { frag_tr_issue<D>(tile, 0, 16 * (db0 + c), lane, f[c][0]); frag_tr_issue<D>(tile, 1, 16 * (db0 + c), lane, f[c][1]); }
+}
+__device__ __forceinline__ void atr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D>
+__device__ __forceinline__ void attn_bwd_dq_dma_body(char* lds, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                     const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                     float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, float scale) {
+    constexpr int KS = D / 32, DB = D / 16, TILE = 64 * 2 * D, NST = AttnPipe<D>::NST;
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * D;
+    const bf16_t* base = qkv + (int64_t)n * L * ld;
+    const int qrow = q0 + (lane & 15);
+    AttnPipe<D> pipe;
+    pipe.init(lane, wave, base + D, ld, base + 2 * D, ld, L >> 6);
+    pipe.issue(lds, 0, 0);
+    if (NST == 3) pipe.issue(lds, 1, 1);
+    bf16x8 Qf[KS], dOf[KS];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Qf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qrow * ld + ks * 32 + 8 * g);
+        dOf[ks] = *reinterpret_cast<const bf16x8*>(d_o + ((int64_t)n * L + qrow) * D + ks * 32 + 8 * g);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + ((int64_t)n * L + qrow) * D + ks * 32 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl = fmaf(bf2f((bf16_t)dOf[ks][e]), bf2f((bf16_t)of[e]), dl);
+    }
+    dl = group_sum(dl);
+    const float ls = lse[(int64_t)n * L + qrow];
+    if (g == 0) delta[(int64_t)n * L + qrow] = dl;
+    f32x4 dQ[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dQ[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int stage = 0;
+    const int ntiles = L >> 6;
+    for (int j = 0; j < ntiles; ++j) {
+        int ns = stage + NST - 1 >= NST ? stage - 1 : stage + NST - 1;
+        pipe.step(lds, j, ns);
+        const char* Kt = lds + stage * 2 * TILE;
+        const char* Vt = Kt + TILE;
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            s[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Kt, 16 * jb, ks, lane), Qf[ks], s[jb], 0, 0, 0);
+                dp[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Vt, 16 * jb, ks, lane), dOf[ks], dp[jb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[jb][r] * scale - ls);
+                s[jb][r] = p * (dp[jb][r] - dl) * scale;                   // dS
+            }
+        const bf16x8 f0 = pack_pair(s[0], s[1]), f1 = pack_pair(s[2], s[3]);
+        constexpr int CH = DB < 4 ? DB : 4;
+#pragma unroll
+        for (int d0 = 0; d0 < DB; d0 += CH) {
+            ATrFrag kf[CH][2];
+            frag_tr_burst<D, CH>(Kt, d0, lane, kf);
+            atr_wait();
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                dQ[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(kf[c][0]), f0, dQ[d0 + c], 0, 0, 0);
+                dQ[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(kf[c][1]), f1, dQ[d0 + c], 0, 0, 0);
+            }
+        }
+        stage = stage + 1 == NST ? 0 : stage + 1;
+    }
+    attn_wait_vmcnt<0>();
+    bf16_t* row = dqkv + ((int64_t)n * L + qrow) * ld;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) store4bf(row + 16 * db + 4 * g, dQ[db]);
+}
+
+template <int D>
+__device__ __forceinline__ void attn_bwd_dkv_dma_body(char* lds, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                      const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                      bf16_t* __restrict__ dqkv, int L, float scale) {
+    constexpr int KS = D / 32, DB = D / 16, TILE = 64 * 2 * D, NST = AttnPipe<D>::NST;
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n = blockIdx.y, kk0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * D;
+    const bf16_t* base = qkv + (int64_t)n * L * ld;
+    const int krow = kk0 + (lane & 15);
+    AttnPipe<D> pipe;
+    pipe.init(lane, wave, base, ld, d_o + (int64_t)n * L * D, D, L >> 6);
+    pipe.issue(lds, 0, 0);
+    if (NST == 3) pipe.issue(lds, 1, 1);
+    bf16x8 Kf[KS], Vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        Kf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)krow * ld + D + ks * 32 + 8 * g);
+        Vf[ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)krow * ld + 2 * D + ks * 32 + 8 * g);
+    }
+    f32x4 dK[DB], dV[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { dK[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float* lse_n = lse + (int64_t)n * L;
+    float* del_n = reinterpret_cast<float*>(lds + NST * 2 * TILE);
+    float* lse_s = del_n + L;                        // the log-sum-exps too: a global load consumed inside the loop would drain the DMA ring
+    for (int q = t >> 2; q < L; q += 64) {           // delta of the image's queries into LDS (see attn_bwd_dkv_body)
+        const int part = t & 3;
+        const bf16_t* po = o + ((int64_t)n * L + q) * D + part * (D / 4);
+        const bf16_t* pg = d_o + ((int64_t)n * L + q) * D + part * (D / 4);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < D / 4; e += 8) {
+            const float8 a = load8(po + e), b = load8(pg + e);
+            sum = fmaf(a.lo.x, b.lo.x, sum); sum = fmaf(a.lo.y, b.lo.y, sum); sum = fmaf(a.lo.z, b.lo.z, sum); sum = fmaf(a.lo.w, b.lo.w, sum);
+            sum = fmaf(a.hi.x, b.hi.x, sum); sum = fmaf(a.hi.y, b.hi.y, sum); sum = fmaf(a.hi.z, b.hi.z, sum); sum = fmaf(a.hi.w, b.hi.w, sum);
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if (part == 0) { del_n[q] = sum; lse_s[q] = lse_n[q]; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the LDS writes above; the loop's first barrier orders them before any read)
+    int stage = 0;
+    const int ntiles = L >> 6;
+    for (int j = 0; j < ntiles; ++j) {
+        int ns = stage + NST - 1 >= NST ? stage - 1 : stage + NST - 1;
+        pipe.step(lds, j, ns);
+        const char* Qt = lds + stage * 2 * TILE;
+        const char* Gt = Qt + TILE;
+        const int q0 = j * 64;
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            s[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Qt, 16 * qb, ks, lane), Kf[ks], s[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<D>(Gt, 16 * qb, ks, lane), Vf[ks], dp[qb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const int qa = q0 + 16 * qb + 4 * g;
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qa);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_n + qa);
+            const float lq[4] = {l4[0], l4[1], l4[2], l4[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[qb][r] * scale - lq[r]);
+                s[qb][r] = p;                                            // P
+                dp[qb][r] = p * (dp[qb][r] - d4[r]) * scale;             // dS
+            }
+        }
+        const bf16x8 p0 = pack_pair(s[0], s[1]), p1 = pack_pair(s[2], s[3]);
+        const bf16x8 e0 = pack_pair(dp[0], dp[1]), e1 = pack_pair(dp[2], dp[3]);
+        constexpr int CH = DB < 2 ? DB : 2;
+#pragma unroll
+        for (int d0 = 0; d0 < DB; d0 += CH) {
+            ATrFrag gf[CH][2], qf[CH][2];
+            frag_tr_burst<D, CH>(Gt, d0, lane, gf);
+            frag_tr_burst<D, CH>(Qt, d0, lane, qf);
+            atr_wait();
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                dV[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(gf[c][0]), p0, dV[d0 + c], 0, 0, 0);
+                dV[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(gf[c][1]), p1, dV[d0 + c], 0, 0, 0);
+                dK[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(qf[c][0]), e0, dK[d0 + c], 0, 0, 0);
+                dK[d0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atr_value(qf[c][1]), e1, dK[d0 + c], 0, 0, 0);
+            }
+        }
+        stage = stage + 1 == NST ? 0 : stage + 1;
+    }
+    attn_wait_vmcnt<0>();
+    bf16_t* row = dqkv + ((int64_t)n * L + krow) * ld;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        store4bf(row + D + 16 * db + 4 * g, dK[db]);
+        store4bf(row + 2 * D + 16 * db + 4 * g, dV[db]);
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                           const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int L, float scale) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    if (blockIdx.z == 0) attn_bwd_dq_dma_body<D>(lds, qkv, o, d_o, lse, delta, dqkv, L, scale);
+    else attn_bwd_dkv_dma_body<D>(lds, qkv, o, d_o, lse, dqkv, L, scale);
+}
+
 // blockIdx.z = 0: dQ (and delta, kept as an output), 1: dK and dV
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
@@ -348,6 +729,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     else attn_bwd_dkv_body<D>(lds, qkv, o, d_o, lse, dqkv, L, scale);
 }
 
+#ifndef MDM_ATTN_DMA
+#define MDM_ATTN_DMA 1
+#endif
 template <int D>
 static int attn_launch(int which, const bf16_t* qkv, bf16_t* o, const bf16_t* d_o, float* lse, float* delta, bf16_t* dqkv,
                        int N, int L, float scale, hipStream_t s) {
@@ -360,9 +744,35 @@ static int attn_launch(int which, const bf16_t* qkv, bf16_t* o, const bf16_t* d_
     }
     dim3 grid((unsigned)cdiv(L, 64), (unsigned)N);
     if (which == 0) {
+        if constexpr (D >= 64) {
+            if (MDM_ATTN_DMA && L % 64 == 0 && L >= 256) {         // several key tiles: K / V prefetched by LDS-DMA
+                constexpr int dma_bytes = (D <= 128 ? 3 : 2) * 2 * 64 * 2 * D;
+                static bool dma_configured = false;
+                if (!dma_configured) {
+                    MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_dma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_bytes));
+                    dma_configured = true;
+                }
+                hipLaunchKernelGGL((attn_fwd_dma_kernel<D>), grid, dim3(256), dma_bytes, s, qkv, o, lse, L, scale);
+                return launch_status("attention");
+            }
+        }
         hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), bytes, s, qkv, o, lse, L, scale);
     } else {
         MDM_REQUIRE(L <= 4096, "attention backward: L=%d > 4096", L);
+        if constexpr (D >= 64) {
+            if (MDM_ATTN_DMA && L % 64 == 0 && L >= 256) {
+                constexpr int dma_bytes = (D <= 128 ? 3 : 2) * 2 * 64 * 2 * D;
+                static bool dma_configured = false;
+                if (!dma_configured) {
+                    MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      dma_bytes + 8 * 4096));
+                    dma_configured = true;
+                }
+                hipLaunchKernelGGL((attn_bwd_dma_kernel<D>), dim3(grid.x, grid.y, 2), dim3(256), dma_bytes + 8 * L, s, qkv, (const bf16_t*)o, d_o,
+                                   (const float*)lse, delta, dqkv, L, scale);
+                return launch_status("attention");
+            }
+        }
         hipLaunchKernelGGL((attn_bwd_kernel<D>), dim3(grid.x, grid.y, 2), dim3(256), bytes + 4 * L, s, qkv, (const bf16_t*)o, d_o,
                            (const float*)lse, delta, dqkv, L, scale);
     }
