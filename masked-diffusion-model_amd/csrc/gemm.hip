@@ -1617,25 +1617,35 @@ __device__ __forceinline__ void load8f(const float* p, float (&o)[8]) {
 }
 // conv_small_body's parked partials -> pixel r, channels 8g .. 8g+7 of its 64 x 32 tile: two accumulator quads of each of the four
 // k-step partials, added in ascending k (fixed order)
+template <int MI, int NI>          // a wave's partial = MI x NI accumulator tiles; pixel half ph = r / (16 MI) (r < 32 MI)
 __device__ __forceinline__ void rows_gather_small(const f32x4* red, const int g, const int r, float (&v)[8]) {
-    const int ph = r >> 5, ti = ((r >> 4) & 1) * 2 + (g >> 1), l0 = (r & 15) + 32 * (g & 1);
+    constexpr int T = MI * NI;
+    const int ph = r / (16 * MI), ti = ((r >> 4) % MI) * NI + (g >> 1), l0 = (r & 15) + 32 * (g & 1);
     {
-        const f32x4 a = red[((ph * 4) * 4 + ti) * 64 + l0], b = red[((ph * 4) * 4 + ti) * 64 + l0 + 16];
+        const f32x4 a = red[((ph * 4) * T + ti) * 64 + l0], b = red[((ph * 4) * T + ti) * 64 + l0 + 16];
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     }
 #pragma unroll
     for (int ks = 1; ks < 4; ++ks) {
-        const f32x4 a = red[((ph * 4 + ks) * 4 + ti) * 64 + l0], b = red[((ph * 4 + ks) * 4 + ti) * 64 + l0 + 16];
+        const f32x4 a = red[((ph * 4 + ks) * T + ti) * 64 + l0], b = red[((ph * 4 + ks) * T + ti) * 64 + l0 + 16];
         v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
     }
 }
+// `act`: this lane's pixel exists (tiles of fewer than 64 pixels leave lanes over: they load valid addresses, contribute zeros to
+// every sum and store nothing)
 template <bool WT, bool P16>
-__device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)[8], const int m0, const int n0, const int g, const int r) {
+__device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)[8], const int m0, const int n0, const int g, const int r_lane,
+                                              const bool act = true) {
     constexpr int P = P16 ? 16 : 64, p_sh = P16 ? 4 : 6;
+    const int r = act ? r_lane : 0;
+    if (!act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
     const int64_t m = (int64_t)m0 + r;
     const int n = n0 + 8 * g, C = d.N;
     const int img = (m0 >> p_sh) + (P16 ? (r >> 4) : 0);
-    const bool first = (r & (P - 1)) == 0;                          // the lane that writes per-image results
+    const bool first = act && (r & (P - 1)) == 0;                   // the lane that writes per-image results
     const float inv_cnt = 1.f / (8.f * (float)P);
     if (d.gnb_x) {
         // ---- GroupNorm backward of the tensor this convolution's input came from (mdm_gemm_can_fuse_gn_bwd: no bias / row / residual)
@@ -1658,30 +1668,30 @@ __device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)
         a2 = img_sum<P16>(a2);
         const float k1 = st.y * a1 * inv_cnt, k2 = st.y * a2 * inv_cnt;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = st.y * ga[e] * gz[e] - fmaf(xh[e], k2, k1);
+        for (int e = 0; e < 8; ++e) o[e] = act ? st.y * ga[e] * gz[e] - fmaf(xh[e], k2, k1) : 0.f;
         // dgamma / dbeta: sums over every pixel of the tile; lane e adds dgamma[n + e], lane 8 + e dbeta[n + e] (one atomic per
         // channel per workgroup, as before)
         float mine = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float dg = tile_sum_from_img<P16>(img_sum<P16>(gz[e] * xh[e])), db = tile_sum_from_img<P16>(img_sum<P16>(gz[e]));
-            mine = r == e ? dg : (r == 8 + e ? db : mine);
+            mine = r_lane == e ? dg : (r_lane == 8 + e ? db : mine);
         }
-        if (r < 16) atomicAdd((r < 8 ? d.gnb_dgamma : d.gnb_dbeta) + n + (r & 7), mine);
+        if (r_lane < 16) atomicAdd((r_lane < 8 ? d.gnb_dgamma : d.gnb_dbeta) + n + (r_lane & 7), mine);
         if (d.gnb_sum_img || d.gnb_sum_all) {                       // uniform: column sums of dx (before any accumulation)
             float cs[8], tot = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 cs[e] = img_sum<P16>(o[e]);
                 const float tt = tile_sum_from_img<P16>(cs[e]);
-                tot = r == e ? tt : tot;
+                tot = r_lane == e ? tt : tot;
             }
             if (d.gnb_sum_img && first) {                           // this workgroup owns (image, channel)
                 float* sp = d.gnb_sum_img + (int64_t)img * d.gnb_sum_ld + n;
                 *reinterpret_cast<float4*>(sp) = make_float4(cs[0], cs[1], cs[2], cs[3]);
                 *reinterpret_cast<float4*>(sp + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
             }
-            if (d.gnb_sum_all && r < 8) atomicAdd(d.gnb_sum_all + n + r, tot);
+            if (d.gnb_sum_all && r_lane < 8) atomicAdd(d.gnb_sum_all + n + r_lane, tot);
         }
         bf16_t* p = reinterpret_cast<bf16_t*>(d.D0) + m * d.ldd0 + n;
         if (d.acc0) {
@@ -1696,7 +1706,7 @@ __device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += old[e];
         }
-        store8_pub<WT>(p, pack8(o));
+        if (act) store8_pub<WT>(p, pack8(o));
         return;
     }
     // ---- forward-type epilogue: scale, bias, time-embedding row, residual, accumulate; optionally the GroupNorm of the result
@@ -1729,7 +1739,7 @@ __device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += old[e];
     }
-    store8_pub<WT>(p, pack8(v));
+    if (act) store8_pub<WT>(p, pack8(v));
     if (d.gnf_out) {
         const int G = d.gnf_G;
         float y[8], ga[8], be[8], o[8];
@@ -1748,7 +1758,7 @@ __device__ __forceinline__ void epilogue_rows(const mdm_gemm_desc& d, float (&v)
             o[e] = fmaf((y[e] - mean) * rstd, ga[e], be[e]);
             if (d.gnf_silu) o[e] = silu_f(o[e]);
         }
-        store8_pub<WT>(reinterpret_cast<bf16_t*>(d.gnf_out) + m * C + n, pack8(o));
+        if (act) store8_pub<WT>(reinterpret_cast<bf16_t*>(d.gnf_out) + m * C + n, pack8(o));
         if (first) {
             float* sp = d.gnf_stats + ((int64_t)img * G + (n >> 3)) * 2;
             sp[0] = mean; sp[1] = rstd;
@@ -3030,9 +3040,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
 #ifndef MDM_SMALL_EPI
 #define MDM_SMALL_EPI 1             // 0: conv_small keeps the LDS epilogues of the halo tiles (A/B builds)
 #endif
-template <int NPW, bool WT = false>
+// BM x BN: 64 x 32, or 32 x 16 on the 4x4 maps (two whole images x two GroupNorm groups: 256 workgroups instead of 64, each streaming a
+// quarter of the bytes -- the loop is bound by what ONE CU takes in)
+template <int NPW, bool WT = false, int BM = 64, int BN = 32>
 __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
-    constexpr int BN = 32, CS = 128, NSB = 3;
+    constexpr int CS = 128, NSB = 3, MI = BM / 32, NI = BN / 16, BPT = BN / 4;     // BPT: 1-KiB pieces of one tap's filter tile
+    static_assert((BM == 64 && BN == 32) || (BM == 32 && BN == 16), "conv_small: 64 x 32 or 32 x 16 tiles");
     constexpr int ROWB = CS * 2, B_TAP = BN * ROWB, STAGE_B = 3 * B_TAP;
     constexpr int HA = (NPW + 1) / 2, HB = NPW - HA;                // halo pieces a wave issues in group 0 / group 1 of a superslab
     MDM_T(const unsigned long long t_entry = stamp_now();)
@@ -3041,14 +3054,14 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
     const int ks = wave & 3, ph = wave >> 2;
     const int OW = d.OW, OH = d.OH, HW2 = OW + 2;
     const int ow_sh = __builtin_ctz(OW), p_sh = ow_sh + __builtin_ctz(OH);
-    const int IMGS = 64 >> p_sh;                                     // whole images per tile: 4 (4x4) or 1 (8x8)
+    const int IMGS = BM >> p_sh;                                     // whole images per tile: 4 / 2 (4x4) or 1 (8x8)
     const int HRI = (OH + 2) * HW2, HR = IMGS * HRI, NPA = (HR + 3) >> 2, ABUF = NPA * 1024;
     const float inv_hw2 = __builtin_amdgcn_rcpf((float)HW2), inv_hri = __builtin_amdgcn_rcpf((float)HRI);
     char* const bring = lds + 2 * ABUF;
     char* const dummy = bring + NSB * STAGE_B;
     const int tiles_n = (d.N + BN - 1) / BN;
     const int bid = xcd_remap(bx, gx);
-    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * 64;
+    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
     const int img0 = m0 >> p_sh;
     const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
     const int NSS = d.Ck / CS;
@@ -3076,8 +3089,9 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
         lds_dma16((apix[k] >= 0 && ss < NSS) ? src : zlane, p < NPA ? abuf + p * 1024 : dummy);
     };
     // ---- filter tile of (tap, superslab): 32 rows (output channels) x 256 B = 8 pieces, one per wave
-    const int bn_l = 4 * wave + (lane >> 4);
-    const bool b_live = n0 + bn_l < d.N;
+    const bool b_wave = wave < BPT;                                 // (16-channel tiles: waves 4 .. 7 issue into the dummy page, the counts stay uniform)
+    const int bn_l = b_wave ? 4 * wave + (lane >> 4) : 0;
+    const bool b_live = b_wave && n0 + bn_l < d.N;
     const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(n0 + bn_l) * d.ldb) +
                         (((lane & 15) ^ (bn_l & 15)) << 4);
     // (Measured and NOT kept: the six dummy DMA slots of the last two groups TOUCHING what the epilogue is going to load -- x / residual,
@@ -3086,7 +3100,7 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
     auto issue_b = [&](int tap, int ss, int lds_off) {
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)ss * CS) * 2;
         const bool live = ss < NSS && b_live;
-        lds_dma16(live ? b_row + off : zlane, ss < NSS ? bring + lds_off + wave * 1024 : dummy);
+        lds_dma16(live ? b_row + off : zlane, (ss < NSS && b_wave) ? bring + lds_off + wave * 1024 : dummy);
     };
 
     // ---- prologue: halo of superslab 0, filter groups 0 and 1
@@ -3099,24 +3113,24 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
 
     // ---- fragment addresses: centre-tap halo row of this lane's pixel in each of its two 16-row blocks; filter rows
     const int kch = ks * 4 + (lane >> 4);                           // 16-byte chunk of this lane inside a 256-byte row
-    int a_hb[2], b_off[2];
+    int a_hb[MI], b_off[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ml = ph * 32 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int ml = ph * (BM / 2) + i * 16 + (lane & 15);
         const int il = ml >> p_sh, mrem = ml - (il << p_sh);
         const int r = mrem >> ow_sh, x = mrem - (r << ow_sh);
         a_hb[i] = il * HRI + (r + 1) * HW2 + x + 1;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NI; ++j) {
         const int nl = j * 16 + (lane & 15);
         b_off[j] = nl * ROWB + ((kch ^ (nl & 15)) << 4);
     }
-    f32x4 acc[2][2];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int stage = 0;
     MDM_T(unsigned long long t_wait = 0, t_bar = 0;)
@@ -3134,19 +3148,19 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
         if ((G3) == 0) { _Pragma("unroll") for (int q = 0; q < HA; ++q) issue_a(q, ss + 1, anext); }               \
         if ((G3) == 1) { _Pragma("unroll") for (int q = 0; q < HB; ++q) issue_a(HA + q, ss + 1, anext); }          \
         const char* Bs = bring + stage * STAGE_B;                                                                  \
-        bf16x8 af[3][2], bfr[3][2];                                                                                \
+        bf16x8 af[3][MI], bfr[3][NI];                                                                              \
         _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                            \
             const int tx = k, ty = (G3);                                                                           \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                         \
                 bfr[k][j] = *reinterpret_cast<const bf16x8*>(Bs + k * B_TAP + b_off[j]);                           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                       \
                 const int hr = a_hb[i] + sgn * ((ty - 1) * HW2 + (tx - 1));                                        \
                 af[k][i] = *reinterpret_cast<const bf16x8*>(acur + hr * ROWB + ((kch ^ (hr & 15)) << 4));          \
             }                                                                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                              \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                     \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[k][j], af[k][i], acc[i][j], 0, 0, 0);  \
         stage = stage + 1 == NSB ? 0 : stage + 1;                                                                  \
     }
@@ -3164,20 +3178,21 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
     {
         f32x4* red = reinterpret_cast<f32x4*>(lds + 16384);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) red[(wave * 4 + i * 2 + j) * 64 + lane] = acc[i][j];
+            for (int j = 0; j < NI; ++j) red[(wave * (MI * NI) + i * NI + j) * 64 + lane] = acc[i][j];
         __syncthreads();
         // C / G == 8 (or no fused GroupNorm): the register epilogue, four waves; anything else: the LDS epilogues of the halo tiles
         const int cpg = d.gnb_x ? d.N / d.gnb_G : (d.gnf_out ? d.N / d.gnf_G : 8);
-        if (MDM_SMALL_EPI && cpg == 8 && (d.N0 & 7) == 0) {                                                         // uniform
-            if (wave < 4) {
+        if ((BM != 64 || MDM_SMALL_EPI) && cpg == 8 && (d.N0 & 7) == 0) {                                           // uniform
+            if (wave < BN / 8) {                                   // one wave per group of eight channels; lane = pixel of the tile
                 float v8[8];
-                rows_gather_small(red, wave, lane, v8);
-                if (p_sh == 4) epilogue_rows<WT, true>(d, v8, m0, n0, wave, lane);
-                else epilogue_rows<WT, false>(d, v8, m0, n0, wave, lane);
+                const bool act = lane < BM;
+                rows_gather_small<MI, NI>(red, wave, act ? lane : 0, v8);
+                if (p_sh == 4) epilogue_rows<WT, true>(d, v8, m0, n0, wave, lane, act);
+                else epilogue_rows<WT, false>(d, v8, m0, n0, wave, lane, act);
             }
-        } else {
+        } else if constexpr (BM == 64 && BN == 32) {
         const int wr = wave >> 1, wc = wave & 1;
         const int src = (wr >> 1) * 4, tile = (wr & 1) * 2 + wc;
         f32x4 v = red[((src + 0) * 4 + tile) * 64 + lane];
@@ -3206,16 +3221,16 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
 #endif
 }
 
-template <int NPW>
+template <int NPW, int BM = 64, int BN = 32>
 __global__ __launch_bounds__(512) void conv_small_kernel(mdm_gemm_desc d) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    conv_small_body<NPW>(d, lds, (int)blockIdx.x, (int)gridDim.x);
+    conv_small_body<NPW, false, BM, BN>(d, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 // conv_small + a 1x1 projection in one launch (the pairs of mdm_gemm_pair on the 4x4 / 8x8 maps)
-template <int NPW>
+template <int NPW, int BM = 64, int BN = 32>
 __global__ __launch_bounds__(512) void conv_pair_small_kernel(mdm_gemm_desc a, mdm_gemm_desc b, int na) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    if ((int)blockIdx.x < na) conv_small_body<NPW>(a, lds, (int)blockIdx.x, na);
+    if ((int)blockIdx.x < na) conv_small_body<NPW, false, BM, BN>(a, lds, (int)blockIdx.x, na);
     else conv_lin2_body<64, 64, 4, 4, 2, 1, true, false>(b, lds, (int)blockIdx.x - na, (int)gridDim.x - na, 0);
 }
 
@@ -3462,14 +3477,14 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(mdm_gemm_desc a, mdm_gem
                                             //    intermittent mismatch was observed (profiles/r04_chain_findings.md): not the default
 #endif
 struct ChainPhase {
-    int kind[2];            // role 0 / role 1 (mdm_gemm_pair): 0 = halo 64x32 (2 pieces per wave), 1 = halo 64x32 (3 pieces), 2 = lin2 64x64, -1 = none
+    int kind[2];            // role 0 / role 1 (mdm_gemm_pair): 0 / 1 = halo 64x32 (2 / 3 pieces per wave), 2 = lin2 64x64, 3 / 4 = conv_small 64x32,
+                            // 5 = conv_small 32x16, -1 = none
     int desc[2];
     int nblk[2];
     int tiles_n[2];         // channel tiles per 64-pixel row tile
-    int img_sh;             // log2(images per row tile): 0 on 8x8 maps, 2 on 4x4
+    int img_sh_role[2];     // log2(images per row tile) of each role: 0 on 8x8 maps, 2 (64-pixel tiles) or 1 (32-pixel tiles) on 4x4
     unsigned target;        // finished blocks per image that complete this phase
     unsigned prev_target;   // ... the phase in front of it (0: nothing to wait for)
-    int pad;
 };
 #ifdef MDM_STAMP
 #define MDM_CHAIN_STAMP_BASE 16384          // records [16384, 32768) of g_stamp_buf: one per (phase, virtual block)
@@ -3492,7 +3507,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const mdm_gemm_desc* __restr
             const int role = vb >= P.nblk[0] ? 1 : 0;
             const int bx = role ? vb - P.nblk[0] : vb, gx = P.nblk[role];
             const int rt = udiv_small(xcd_remap(bx, gx), P.tiles_n[role]);     // the row tile the body will compute (same arithmetic)
-            const int nimg = 1 << P.img_sh, img0 = rt << P.img_sh;
+            const int nimg = 1 << P.img_sh_role[role], img0 = rt << P.img_sh_role[role];
             MDM_T(const unsigned long long t_w0 = stamp_now();)
             if (P.prev_target != 0u) {
                 if (t < 64) {                                   // wave 0: lane i polls the counter of image img0 + i
@@ -3520,6 +3535,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const mdm_gemm_desc* __restr
                 else if (kind == 1) conv_halo_body<64, 3, 32, 3, 3, bf16_t, false, WT>(d, lds, bx, gx);
                 else if (kind == 3) conv_small_body<4, WT>(d, lds, bx, gx);
                 else if (kind == 4) conv_small_body<5, WT>(d, lds, bx, gx);
+                else if (kind == 5) conv_small_body<3, WT, 32, 16>(d, lds, bx, gx);
                 else conv_lin2_body<64, 64, 4, 4, 2, 1, true, false, WT>(d, lds, bx, gx, 0);
             }
             MDM_T(const unsigned long long t_b1 = stamp_now();)
@@ -3686,21 +3702,25 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // TG = 3: 
     hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T, SPLIT>), grid, dim3(512), bytes, s, d);
     return 0;
 }
-static int small_pieces(const mdm_gemm_desc& d) {           // 1-KiB pieces of one conv_small halo buffer (256-byte pixel rows)
-    const int imgs = 64 / (d.OH * d.OW);
+static int small_pieces(const mdm_gemm_desc& d, int bm = 64) {           // 1-KiB pieces of one conv_small halo buffer (256-byte pixel rows)
+    const int imgs = bm / (d.OH * d.OW);
     return (imgs * (d.OH + 2) * (d.OW + 2) + 3) / 4;
 }
-static int small_lds_bytes(const mdm_gemm_desc& d) { return 2 * small_pieces(d) * 1024 + 3 * 3 * 32 * 256 + 1024; }
-template <int NPW>
+static int small_lds_bytes(const mdm_gemm_desc& d, int bm = 64, int bn = 32) {
+    const int bytes = 2 * small_pieces(d, bm) * 1024 + 3 * 3 * bn * 256 + 1024;
+    return bytes < 16384 + 8 * 1024 ? 16384 + 8 * 1024 : bytes;          // (the parked partials: 8 waves x <= 1 KiB behind the first 16 KiB)
+}
+template <int NPW, int BM = 64, int BN = 32>
 static int launch_small(const mdm_gemm_desc& d, hipStream_t s) {
-    const int bytes = small_lds_bytes(d);
-    MDM_REQUIRE(small_pieces(d) <= 8 * NPW && bytes <= 160 * 1024 && bytes >= 16384 + 65536 + 4096 + 512, "conv_small: tile does not fit (%d bytes)", bytes);
+    const int bytes = small_lds_bytes(d, BM, BN);
+    MDM_REQUIRE(small_pieces(d, BM) <= 8 * NPW && bytes <= 160 * 1024 && (BM != 64 || bytes >= 16384 + 65536 + 4096 + 512),
+                "conv_small: tile does not fit (%d bytes)", bytes);
     static int configured = 0;
     if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<NPW, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
-    hipLaunchKernelGGL((conv_small_kernel<NPW>), dim3((unsigned)((int64_t)(d.M / 64) * cdiv(d.N, 32))), dim3(512), bytes, s, d);
+    hipLaunchKernelGGL((conv_small_kernel<NPW, BM, BN>), dim3((unsigned)((int64_t)(d.M / BM) * cdiv(d.N, BN))), dim3(512), bytes, s, d);
     return 0;
 }
 // 0: not eligible, else the pixel tile (64, 128 or 256)
@@ -3983,7 +4003,10 @@ static bool lin2_gn_tile(const mdm_gemm_desc& d) {
            d.C0 % 64 == 0 && d.C1 % 64 == 0 && d.Ck == d.C0 + d.C1 && d.N0 % 8 == 0 && !d.out_f32 && d.splitk <= 1;
 }
 enum ConvVar { CV_NONE = 0, CV_H256_4, CV_H256_6, CV_H128_3, CV_H128_4, CV_H128_6, CV_H64_2_32, CV_H64_3_32, CV_H64_2_64, CV_H64_3_64,
-               CV_L128, CV_L64x128, CV_L64, CV_S64_4, CV_S64_5 };
+               CV_L128, CV_L64x128, CV_L64, CV_S64_4, CV_S64_5, CV_S32_3 };
+#ifndef MDM_SMALL_32X16
+#define MDM_SMALL_32X16 1           // 0: the 4x4 maps stay on conv_small's 64 x 32 tiles (A/B builds)
+#endif
 #ifndef MDM_SMALL_CONV
 #define MDM_SMALL_CONV 1            // 0: the 4x4 / 8x8 maps stay on conv_halo_body's 64 x 32 tiles (A/B builds)
 #endif
@@ -4002,7 +4025,15 @@ static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned 
         if (d.N % 32 == 0 && (!(d.gnb_x || d.gnf_out) || d.N / (d.gnb_x ? d.gnb_G : d.gnf_G) <= 32)) {
             // 128-channel superslabs with the reduction split over the waves (conv_small_body) where the channel counts allow
             const int spw = (small_pieces(d) + 7) / 8;
-            if (MDM_SMALL_CONV && d.Ck % 128 == 0 && d.C0 % 128 == 0 && d.C1 % 128 == 0 && spw <= 5) return spw <= 4 ? CV_S64_4 : CV_S64_5;
+            if (MDM_SMALL_CONV && d.Ck % 128 == 0 && d.C0 % 128 == 0 && d.C1 % 128 == 0 && spw <= 5) {
+                // 4x4 maps: 32 pixels (two whole images) x 16 channels (two GroupNorm groups of eight) -- four times the workgroups, each
+                // streaming a quarter of the filter bytes; its epilogue is the register one only (C / G == 8 where a GroupNorm is fused)
+                const int cpg = d.gnb_x ? d.N / d.gnb_G : (d.gnf_out ? d.N / d.gnf_G : 8);
+                if (MDM_SMALL_32X16 && d.OH * d.OW == 16 && d.M % 32 == 0 && d.N % 16 == 0 && cpg == 8 && (d.N0 & 7) == 0 &&
+                    (int64_t)(d.M / 64) * (d.N / 32) < kBigMinTiles && (small_pieces(d, 32) + 7) / 8 <= 3)
+                    return CV_S32_3;
+                return spw <= 4 ? CV_S64_4 : CV_S64_5;
+            }
             return npw <= 2 ? CV_H64_2_32 : CV_H64_3_32;
         }
         return npw <= 2 ? CV_H64_2_64 : CV_H64_3_64;
@@ -4114,6 +4145,7 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             case CV_H64_3_64: rc = launch_halo<64, 3, 3>(d, s); break;
             case CV_S64_4: rc = launch_small<4>(d, s); break;
             case CV_S64_5: rc = launch_small<5>(d, s); break;
+            case CV_S32_3: rc = launch_small<3, 32, 16>(d, s); break;
             case CV_L128: rc = launch_lin2<128, 128, 3, 4, 2>(d, grid, s); break;
             case CV_L64x128: rc = launch_lin2<64, 128, 3, 2, 4>(d, g2, s); break;
             default: rc = launch_lin2<64, 64, 4, 4, 2>(d, grid, s); break;
@@ -4191,6 +4223,10 @@ static int chain_kind(const mdm_gemm_desc* dh, Resolved& r, int* lds_bytes) {
         *lds_bytes = small_lds_bytes(d);
         return cv == CV_S64_4 ? 3 : 4;
     }
+    if (cv == CV_S32_3) {
+        *lds_bytes = small_lds_bytes(d, 32, 16);
+        return 5;
+    }
     if (cv == CV_L64 && r.tiles < (1ll << 20)) {
         int bytes = 4 * (64 + 64) * 64 * 2;                                        // as launch_lin2<64, 64, 4, 4, 2>
         if (d.gnb_x && bytes < 16384 + 65536 + 4096 + 512) bytes = 16384 + 65536 + 4096 + 512;
@@ -4228,19 +4264,19 @@ static int launch_pair(const mdm_gemm_desc& a, const mdm_gemm_desc& b, int nb, h
     return 0;
 }
 
-template <int NPW>
+template <int NPW, int BM = 64, int BN = 32>
 static int launch_pair_small(const mdm_gemm_desc& a, const mdm_gemm_desc& b, int nb, hipStream_t s) {
-    int bytes = small_lds_bytes(a);
+    int bytes = small_lds_bytes(a, BM, BN);
     constexpr int lin_bytes = 4 * (64 + 64) * 64 * 2;
     if (bytes < lin_bytes) bytes = lin_bytes;
-    MDM_REQUIRE(small_pieces(a) <= 8 * NPW && bytes <= 160 * 1024, "conv_pair_small: tile does not fit (%d bytes)", bytes);
+    MDM_REQUIRE(small_pieces(a, BM) <= 8 * NPW && bytes <= 160 * 1024, "conv_pair_small: tile does not fit (%d bytes)", bytes);
     static int configured = 0;
     if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_small_kernel<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_small_kernel<NPW, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = bytes;
     }
-    const int na = (int)((int64_t)(a.M / 64) * (a.N / 32));
-    hipLaunchKernelGGL((conv_pair_small_kernel<NPW>), dim3((unsigned)(na + nb)), dim3(512), bytes, s, a, b, na);
+    const int na = (int)((int64_t)(a.M / BM) * (a.N / BN));
+    hipLaunchKernelGGL((conv_pair_small_kernel<NPW, BM, BN>), dim3((unsigned)(na + nb)), dim3(512), bytes, s, a, b, na);
     return 0;
 }
 
@@ -4262,6 +4298,7 @@ extern "C" int mdm_gemm_pair(const mdm_gemm_desc* a_host, const mdm_gemm_desc* b
         const int nb64 = (int)rb.tiles, nb64x128 = (int)((int64_t)cdiv(b.M, 64) * cdiv(b.N, 128));
         if (va == CV_S64_4 && vb == CV_L64) rc = launch_pair_small<4>(a, b, nb64, s);
         else if (va == CV_S64_5 && vb == CV_L64) rc = launch_pair_small<5>(a, b, nb64, s);
+        else if (va == CV_S32_3 && vb == CV_L64) rc = launch_pair_small<3, 32, 16>(a, b, nb64, s);
         else if (va == CV_H64_2_32 && vb == CV_L64) rc = launch_pair<64, 2, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H64_3_32 && vb == CV_L64) rc = launch_pair<64, 3, 32, 3, 64, 64, 4, 4, 2>(a, b, nb64, s);
         else if (va == CV_H128_3 && vb == CV_L64x128) rc = launch_pair<128, 3, 64, 3, 64, 128, 3, 2, 4>(a, b, nb64x128, s);
@@ -4305,7 +4342,7 @@ extern "C" int mdm_chain_create(const mdm_gemm_desc* descs_host, const int* role
     for (int p = 0; p < n_phases; ++p) {
         MDM_REQUIRE(roles[p] == 1 || roles[p] == 2, "chain_create: phase %d has %d descriptors (1 or 2)", p, roles[p]);
         ChainPhase& P = ph[(size_t)p];
-        P.kind[1] = -1; P.desc[1] = 0; P.nblk[1] = 0; P.tiles_n[1] = 1; P.pad = 0;
+        P.kind[1] = -1; P.desc[1] = 0; P.nblk[1] = 0; P.tiles_n[1] = 1; P.img_sh_role[0] = P.img_sh_role[1] = 0;
         MDM_REQUIRE(mdm_chain_accepts(descs_host + di, roles[p] == 2 ? descs_host + di + 1 : nullptr) == 1,
                     "chain_create: phase %d is not a chain link (mdm_chain_accepts)", p);
         unsigned target = 0;
@@ -4314,11 +4351,11 @@ extern "C" int mdm_chain_create(const mdm_gemm_desc* descs_host, const int* role
             int lb = 0;
             const int k = chain_kind(descs_host + di + q, r, &lb);
             const mdm_gemm_desc& d = r.d;
-            const int Pix = d.OH * d.OW, imgs = d.M / Pix, bn = k == 2 ? 64 : 32;
+            const int Pix = d.OH * d.OW, imgs = d.M / Pix, bn = k == 2 ? 64 : (k == 5 ? 16 : 32), bm = k == 5 ? 32 : 64;
             MDM_REQUIRE(n_img == 0 || n_img == imgs, "chain_create: phase %d works on %d images, the chain on %d", p, imgs, n_img);
             n_img = imgs;
-            P.kind[q] = k; P.desc[q] = (int)ds.size(); P.tiles_n[q] = cdiv(d.N, bn); P.nblk[q] = (d.M / 64) * P.tiles_n[q];
-            P.img_sh = Pix == 64 ? 0 : 2;
+            P.kind[q] = k; P.desc[q] = (int)ds.size(); P.tiles_n[q] = cdiv(d.N, bn); P.nblk[q] = (d.M / bm) * P.tiles_n[q];
+            P.img_sh_role[q] = Pix == 64 ? 0 : (bm == 32 ? 1 : 2);
             target += (unsigned)P.tiles_n[q];
             lds_max = lb > lds_max ? lb : lds_max;
             ds.push_back(d);

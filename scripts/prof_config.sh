@@ -5,7 +5,7 @@
 CFG=${1:-cfg4}
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/prof_$CFG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/run -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sampler --no-roofline --config $CFG > $OUT/bench.json 2> $OUT/bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/run -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sampler --no-roofline --windows 0 --config $CFG > $OUT/bench.json 2> $OUT/bench.log
 cd $R
 cp $(ls -t $OUT/run/*/*kernel_stats.csv | head -1) $OUT/stats.csv
 python3 - "$OUT/stats.csv" <<'PY'
