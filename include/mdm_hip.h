@@ -163,7 +163,8 @@ int mdm_gemm_can_fuse_gn_fwd(const mdm_gemm_desc* desc_host, int G);
  * and tile_parts_reduce_kernel, which adds the fp32 partial slots of the tiles a share boundary cut.  The slots live in
  * dev_buf too (they are part of *need_bytes_out: ~80 MB for the whole cfg2 backward), descriptor.splitk / ws of such a member
  * are ignored.  Same results as the per-tap form up to fp32 summation order.  Environment: MDM_WGRAD_TAPS=0 keeps every layer
- * on the per-tap kernels; MDM_TAPS_DEBUG=1 prints the schedule of each group.
+ * on the per-tap kernels; MDM_TAPS_DEBUG=1 prints the schedule of each group; MDM_WGRAD_RESERVE_CUS=r builds the persistent nine-tap
+ * launch for CUs - r workgroups (data-parallel runs: room for the collective's kernels beside it).
  * ------------------------------------------------------------------------- */
 int mdm_wgrad_group_accepts(const mdm_gemm_desc* desc_host);
 int mdm_wgrad_group_create(const mdm_gemm_desc* descs_host, int n, void* dev_buf, int64_t dev_bytes,

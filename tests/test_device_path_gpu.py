@@ -172,7 +172,8 @@ def test_sampler_250_steps_rel_l2_vs_oracle(dt, bound, T):
         # bf16 storage does NOT hold north_star's 1e-3 over 250 momentum steps on this net (measured: rel-L2 ~0.5, the
         # momentum update x_t += D_{t-1} - D_t integrates every step's rounding): the fp32 path is the sampler of
         # record, bf16 is reported as the fast approximate mode.  Here: it runs, stays finite and bounded.
-        assert rel < 2.0 and float(x0.abs().max()) < 1e3, rel
+        # (measured 0.37-0.57 depending on the box: the bar is 3x the smaller figure)
+        assert rel < 1.1 and float(x0.abs().max()) < 1e3, rel
 
 
 @pytest.mark.parametrize("dt,dep,mode,T", [(0, "independent", "base_momentum", 1000), (1, "independent", "base_momentum", 1000),
@@ -233,8 +234,8 @@ def test_sampler_1000_steps_teacher_forced_vs_oracle(dt, dep, mode, T):
     for key, (mx, med) in worst.items():
         if dt == 0:
             assert mx < 1e-3 and med < 5e-5, (key, mx, med)
-        else:
-            assert mx < 2e-1 and med < 5e-2, (key, mx, med)
+        else:       # bf16 storage: measured worst 2.6e-2, median 9e-4 (profiles/r04_parity_notes.jsonl): bars at 3x
+            assert mx < 8e-2 and med < 3e-3, (key, mx, med)
 
 
 # ------------------------------------------------------------------------------------------- Trainer.train()
@@ -591,5 +592,6 @@ def test_sampler_1000_steps_free_running_on_trained_weights(dep, mode, prec):
     if (dep, mode) == ("independent", "base_momentum"):
         return                                  # explosive by construction (docstring): recorded only
     assert yard < 1e-4, yard                    # the configuration is well conditioned: the claim is testable
-    if prec != "bf16":
-        assert rel < 1e-3, (rel, yard)
+    # north_star's bar is 1e-3; measured (profiles/r04_parity_notes.jsonl) fp32 <= 1.6e-5, split products <= 4.3e-5, bf16 storage
+    # 3.9e-2 / 0.20 / 2.7e-2: bars at <= 3x the worst of the three configurations
+    assert rel < {"f32": 5e-5, "f32_split": 1.5e-4, "bf16": 0.6}[prec], (rel, yard)

@@ -314,3 +314,30 @@ def test_reference_param_order_is_the_modules_registration_order():
     for cfg in (unet6_config(32), dict(in_channels=4, hid_channels=32, out_channels=4, ch_multipliers=[1, 2, 2],
                                        num_res_blocks=1, apply_attn=[True, True, True])):
         assert UNet(cfg, 1, 32, 32, _dry=True).reference_param_order() == list(param_shapes(cfg))
+
+
+def test_chain_acceptance_and_size_query_on_the_host():
+    """mdm_chain_accepts / mdm_chain_create's size query are host logic (no launch): a 4x4 and an 8x8 3x3 convolution of the trunk and
+    their 1x1 partner are chain links, a 16x16 layer is not; the size query answers without a device buffer."""
+    import ctypes as C
+    from mdm import _lib, ops
+    lib = _lib.load()
+
+    def desc(H, C0, Cout, k=3, N=32):
+        pd = k // 2
+        g = ops.ConvGeom(N=N, IH=H, IW=H, C0=C0, C1=0, Cout=Cout, KH=k, KW=k, pad_t=pd, pad_l=pd, pad_b=pd, pad_r=pd)
+        f = ops.conv_fwd_fields(_lib.BF16, g, 16, None, 16, 16, 16)       # dummy non-null pointers: nothing is launched
+        f.pop("_flops")
+        return _lib._desc(f)
+    a4, a8, a16, l8 = desc(4, 256, 256), desc(8, 256, 256), desc(16, 256, 256), desc(8, 512, 256, k=1)
+    assert lib.mdm_chain_accepts(C.byref(a4), None) == 1 and lib.mdm_chain_accepts(C.byref(a8), None) == 1
+    assert lib.mdm_chain_accepts(C.byref(a16), None) == 0
+    assert lib.mdm_chain_accepts(C.byref(a8), C.byref(l8)) == 1 and lib.mdm_chain_accepts(C.byref(l8), C.byref(a8)) == 0
+    arr = (_lib.GemmDesc * 3)()
+    for i, d in enumerate((a8, l8, a8)):
+        C.memmove(C.byref(arr, i * C.sizeof(_lib.GemmDesc)), C.byref(d), C.sizeof(_lib.GemmDesc))
+    roles = (C.c_int32 * 2)(2, 1)
+    need, h = C.c_int64(), C.c_void_p()
+    assert lib.mdm_chain_create(arr, roles, 2, None, 0, C.byref(need), C.byref(h)) == 0
+    assert need.value > 3 * C.sizeof(_lib.GemmDesc) and not h.value
+    assert lib.mdm_groupnorm_bwd_ws_floats(_lib.F32, 4, 256) == 3 * 4 * 256 and lib.mdm_groupnorm_bwd_ws_floats(_lib.BF16, 4, 256) == 0

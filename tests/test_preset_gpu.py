@@ -52,7 +52,8 @@ def _check_grads(grads, want, tol_g, tag):
 
 
 @pytest.mark.parametrize("n", [4, 32])
-@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
+# bf16 bars at <= 3x the measured values (profiles/r04_parity_notes.jsonl: y 1.0e-2, all gradients 1.6e-2, worst tensor 2.8e-2)
+@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 3e-2, 4e-2)])
 def test_preset_forward_and_all_gradients_eager_and_graph(n, dt, tol_y, tol_g):
     from mdm import _lib, ops
     from mdm import unet as U

@@ -170,7 +170,9 @@ CFG3_FULL = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers
 @pytest.mark.parametrize("name,cfg,hw,n", [("cfg4_attn_everywhere_C4", CFG4_TINY, 32, 2), ("cfg3_64x64", CFG3_TINY, 64, 2),
                                            ("preset_widths_16x16", CFG_WIDE, 16, 4), ("cfg4_full_width", CFG4_FULL, 32, 2),
                                            ("cfg3_full_width_64x64", CFG3_FULL, 64, 2)])
-@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
+# bf16 bars at <= 3x the measured values (profiles/r04_parity_notes.jsonl: y <= 1.4e-2, all gradients <= 2.2e-2; the worst single tensor is
+# 0.09 on the 4-channel cfg4 model -- tiny tensors --, <= 0.04 on the others)
+@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 6e-2)])
 def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, tol_g):
     from mdm import ops
     from mdm import unet as U
@@ -200,10 +202,10 @@ def test_other_configs_forward_backward_vs_oracle(name, cfg, hw, n, dt, tol_y, t
     worst = max((_rel(grads[k], want[k]), k) for k in want if float(want[k].norm()) > 1e-2 * med)
     from _notes import note
     note("other_configs", dict(name=name, dtype=dt, rel_l2_y=_rel(y, yo.detach()), rel_l2_grads=_rel(a, b), worst_tensor=worst[0], which=worst[1]))
-    assert worst[0] < 2 * tol_g, worst
+    assert worst[0] < (2 * tol_g if dt == 0 else (0.25 if name == "cfg4_attn_everywhere_C4" else 0.12)), worst
 
 
-@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 4e-2, 1e-1)])
+@pytest.mark.parametrize("dt,tol_y,tol_g", [(0, 3e-4, 3e-3), (1, 2.5e-2, 1e-1)])      # bf16 y: 8.5e-3 measured
 def test_preset_width_slice_vs_reference(golden, dt, tol_y, tol_g):
     """A one-level net at the preset's width (hid 256: res blocks 256->256 and 512->256, attention d = 256, 8x8 maps):
     forward, input gradient, per-tensor gradient norms and a stored subset of gradients of the REFERENCE itself."""
