@@ -1593,6 +1593,10 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
 // loop of 11 000 (in-kernel stamps, profiles/r04_small_conv_stamps.txt).  Same arithmetic: statistics in two passes over the
 // bf16-rounded values (forward), the gn_bwd_reg_kernel formulas (backward); sums in a fixed (butterfly) order.
 // Requires C / G == 8 where a GroupNorm is fused, N0 % 8 == 0.  P16: 4x4 maps (an image = 16 lanes), else 8x8 (64 lanes).
+// (Measured and NOT kept, three ways of fetching the epilogue's vectors -- x / residual, the accumulate tensors -- early: plain loads at
+//  KERNEL ENTRY (loads return in order: the loop's first counted wait then waits for HBM: 3.535 -> 3.594 ms/step); touching the lines
+//  through the dummy DMA slots of the last TWO groups (3.703 -> 3.738) or of the LAST group only (3.523 -> 3.553): the epilogue is not
+//  waiting for cold lines.)
 // ----------------------------------------------------------------------------
 template <bool P16>
 __device__ __forceinline__ float img_sum(float v) {                // sum over the lanes of one image, result in every lane of it
@@ -3094,9 +3098,6 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
     const bool b_live = b_wave && n0 + bn_l < d.N;
     const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + (int64_t)(n0 + bn_l) * d.ldb) +
                         (((lane & 15) ^ (bn_l & 15)) << 4);
-    // (Measured and NOT kept: the six dummy DMA slots of the last two groups TOUCHING what the epilogue is going to load -- x / residual,
-    //  the destination of an accumulate, the extra addend -- so that those cold lines are in L2 by then: the epilogue got 450 cycles
-    //  shorter, the loop 2 000 longer (its final vmcnt(0) then waits for HBM): 3.703 -> 3.738 ms/step.)
     auto issue_b = [&](int tap, int ss, int lds_off) {
         const int64_t off = ((int64_t)tap * d.wtap + (int64_t)ss * CS) * 2;
         const bool live = ss < NSS && b_live;
@@ -4040,6 +4041,8 @@ static ConvVar conv_variant(const mdm_gemm_desc& d, const Resolved& r, unsigned 
     }
     if ((d.gnb_x || d.gnf_out) && lin2_gn_tile(d)) return CV_L64;      // the fused epilogues live on the 64 x 64 tile
     if (r.big) return CV_L128;
+    // (the qkv projection of the 8x8 maps is 192 such tiles -- 384 tiles of 64 x 64 = 1.5 rounds today; taking them from 180 on was level:
+    //  3.582 vs 3.586 ms/step)
     if (d.N >= 128 && t_mid >= kBigMinTiles) return CV_L64x128;
     return CV_L64;
 }
