@@ -1595,8 +1595,10 @@ __device__ __forceinline__ void epilogue_tile_gnf(const mdm_gemm_desc& d, char* 
 // Requires C / G == 8 where a GroupNorm is fused, N0 % 8 == 0.  P16: 4x4 maps (an image = 16 lanes), else 8x8 (64 lanes).
 // (Measured and NOT kept, three ways of fetching the epilogue's vectors -- x / residual, the accumulate tensors -- early: plain loads at
 //  KERNEL ENTRY (loads return in order: the loop's first counted wait then waits for HBM: 3.535 -> 3.594 ms/step); touching the lines
-//  through the dummy DMA slots of the last TWO groups (3.703 -> 3.738) or of the LAST group only (3.523 -> 3.553): the epilogue is not
-//  waiting for cold lines.)
+//  through the dummy DMA slots of the last TWO groups (3.703 -> 3.738) or of the LAST group only (3.523 -> 3.553); and ALL of the
+//  epilogue's global loads issued in one burst in front of the barrier and the LDS gather (3.553 -> 3.565): the epilogue is not waiting
+//  for memory.  Stamps (32 x 16 tiles, 4x4 maps): partials parked + barrier 330 cycles, gather 900, epilogue_rows 4 700 (forward
+//  GroupNorm) / 7 300 (backward), drain 900.)
 // ----------------------------------------------------------------------------
 template <bool P16>
 __device__ __forceinline__ float img_sum(float v) {                // sum over the lanes of one image, result in every lane of it
@@ -3172,7 +3174,7 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
     }
 #undef MDM_SMALL_GROUP
     wait_vmcnt<0>();
-    MDM_T(const unsigned long long t_loop_end = stamp_now();)
+    MDM_T(const unsigned long long t_loop_end = stamp_now(); unsigned long long t_e1 = 0, t_e2 = 0, t_e3 = 0;)
     __syncthreads();
     // ---- the waves' partial sums meet in LDS: wave (ks, ph) parks its 2 x 2 tiles, wave (wr, wc) of the epilogue layout adds the four
     // k-steps of ITS 16 x 16 tile in ascending order (fixed summation order); the scratch sits behind the epilogue's fp32 tile
@@ -3183,6 +3185,7 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
 #pragma unroll
             for (int j = 0; j < NI; ++j) red[(wave * (MI * NI) + i * NI + j) * 64 + lane] = acc[i][j];
         __syncthreads();
+        MDM_T(t_e1 = stamp_now();)
         // C / G == 8 (or no fused GroupNorm): the register epilogue, four waves; anything else: the LDS epilogues of the halo tiles
         const int cpg = d.gnb_x ? d.N / d.gnb_G : (d.gnf_out ? d.N / d.gnf_G : 8);
         if ((BM != 64 || MDM_SMALL_EPI) && cpg == 8 && (d.N0 & 7) == 0) {                                           // uniform
@@ -3190,8 +3193,10 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
                 float v8[8];
                 const bool act = lane < BM;
                 rows_gather_small<MI, NI>(red, wave, act ? lane : 0, v8);
+                MDM_T(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_e2 = stamp_now();)
                 if (p_sh == 4) epilogue_rows<WT, true>(d, v8, m0, n0, wave, lane, act);
                 else epilogue_rows<WT, false>(d, v8, m0, n0, wave, lane, act);
+                MDM_T(t_e3 = stamp_now();)
             }
         } else if constexpr (BM == 64 && BN == 32) {
         const int wr = wave >> 1, wc = wave & 1;
@@ -3217,6 +3222,7 @@ __device__ __forceinline__ void conv_small_body(const mdm_gemm_desc& d, char* ld
             unsigned long long* r = g_stamp_buf + widx * 32;
             r[0] = t_wait; r[1] = t_bar; r[2] = 0; r[3] = 0; r[4] = NSS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
             r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
+            r[11] = t_e1 - t_loop_end; r[12] = t_e2 ? t_e2 - t_e1 : 0; r[13] = t_e3 ? t_e3 - t_e2 : 0; r[14] = t_e3 ? stamp_now() - t_e3 : 0;
         }
     }
 #endif

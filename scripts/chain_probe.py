@@ -119,6 +119,10 @@ def stamps():
             md = lambda k: int(np.median(body[:, k]))
             print(f"{tag}: body stamps over {len(body)} waves (median): entry->loop {md(8)}  loop {md(6)} ({md(4)} taps: vmcnt wait {md(0)}, barrier {md(1)})  "
                   f"loop end->body end {md(9)}")
+            ep = body[body[:, 13] > 0]
+            if len(ep):      # conv_small's epilogue waves: park + barrier / gather / epilogue_rows / drain
+                me = lambda k: int(np.median(ep[:, k]))
+                print(f"{tag}:   conv_small tail on {len(ep)} epilogue waves (median): partials parked + barrier {me(11)}  gather {me(12)}  epilogue_rows {me(13)}  drain {me(14)}")
         a = full[16384:]
         t_first = None
         print(f"{tag}: chain of {c.n} phases, status {c.status()}  (cycles of s_memtime; ~2.1 GHz under load, 100 MHz if the counter is the constant one)")
