@@ -13,10 +13,26 @@ q = lambda t: t.to(bf).to(torch.float32)
 nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
 up = lambda t: t.to(dev, bf)
 rel = lambda a, b: float((a.float().cpu() - b).norm() / (b.norm() + 1e-12))
-def run(n_cases, seed, verbose=True):
-  random.seed(seed)
+def small_map_cases():
+  """Every combination the small-map kernels see (conv_small_body on 64 x 32 and 32 x 16 tiles, its pair / fallback paths): 4x4 and 8x8 maps,
+  128- / 256-channel sources with and without a second (concatenated) source, folded upsample, several batch sizes."""
   cases = []
-  for _ in range(n_cases):
+  for H in (4, 8):
+      for N in (2, 4, 32):
+          for (C0, C1) in ((128, 0), (256, 0), (128, 128), (256, 256), (256, 128)):
+              for Co in (128, 256):
+                  for u in ((0, 1) if C1 == 0 else (0,)):
+                      if N == 32 and C0 + C1 == 512 and Co == 128:
+                          continue                      # keep the sweep short: the widest reduction once per map size
+                      cases.append((N, H, C0, C1, Co, 3, 1, u))
+  return cases
+
+
+def run(n_cases, seed, verbose=True, cases=None):
+  random.seed(seed)
+  given = cases is not None
+  cases = list(cases) if given else []
+  for _ in range(0 if given else n_cases):
       N = random.choice([1, 2, 3, 5, 8, 16, 32]); H = random.choice([4, 8, 16, 32])
       C0 = random.choice([8, 24, 64, 128, 192, 256]); C1 = random.choice([0, 0, 0, 64, 128]); Co = random.choice([8, 40, 64, 128, 256])
       k = random.choice([1, 3, 3, 3]); s = random.choice([1, 1, 1, 2]) if k == 3 else 1; u = random.choice([0, 0, 0, 1]) if (k == 3 and s == 1 and C1 == 0) else 0
