@@ -232,6 +232,8 @@ class Sampler:
             raise UnboundLocalError(f"momentum_adaptive={mode!r} does not run upstream (D4)")
         hist_mode = getattr(a, "sample_history", True)
         fused = isinstance(model, UNet)
+        if fused and getattr(a, "sampler_uniform_t", True):
+            model = model.with_uniform_t()      # every reverse step passes ONE timestep for the whole batch (sampler.py:137-145)
         if fused:
             assert (model.N, model.H, model.W) == (n, hw, hw), "UNet plan was built for another batch/extent"
         x_t = (latent if latent is not None else self._get_latent_initial(model)).to(dev, torch.float32).contiguous()

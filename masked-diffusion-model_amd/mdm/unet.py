@@ -228,7 +228,7 @@ class _Conv:
         n, st, g = self.net, self.net.store, self.g
         rv, ld = (None, 0)
         if self.fc_slot is not None:
-            rv, ld = n.T_all[:, self.fc_slot:], n.fc_total
+            rv, ld = n.T_all[:, self.fc_slot:], (0 if n.uniform_t else n.fc_total)     # uniform_t: ONE projection row for every image
         return ops.conv_fwd_fields(n.dt, g, self.src0.data, self.src1.data if self.src1 else None, st.w(self.name + ".weight"),
                                    st.f(self.name + ".bias"), self.out.data, rowvec=rv, rv_ld=ld,
                                    resid=self.resid.data if self.resid else None, ws=n.splitk_ws,
@@ -447,15 +447,20 @@ class _Temb:
         st.declare(self.l2 + ".weight", "lin", (self.temb, self.temb), (self.temb, self.temb))
         st.declare(self.l2 + ".bias", "vec", (self.temb,), (self.temb,))
 
+    def _rows(self):
+        """Rows of the time-embedding path: the batch -- or ONE when the plan was built for a timestep shared by the whole batch
+        (`UNet(uniform_t=True)`: the reverse sampler; every image then reads projection row 0)."""
+        return 1 if self.net.uniform_t else self.net.N
+
     def _skinny(self):
         """The dedicated small-batch kernels (mdm_skinny_*) take this path; larger batches use the general contraction."""
-        n = self.net
-        return (self.hid % 2 == 0 and ops.skinny_supported(n.N, self.temb, self.hid) and ops.skinny_supported(n.N, self.temb, self.temb)
-                and ops.skinny_supported(n.N, self.fc_total, self.temb) and ops.skinny_supported(n.N, self.temb, self.fc_total))
+        N = self._rows()
+        return (self.hid % 2 == 0 and ops.skinny_supported(N, self.temb, self.hid) and ops.skinny_supported(N, self.temb, self.temb)
+                and ops.skinny_supported(N, self.fc_total, self.temb) and ops.skinny_supported(N, self.temb, self.fc_total))
 
     def fwd(self):
         n, st = self.net, self.net.store
-        N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
+        N, hid, te, ft = self._rows(), self.hid, self.temb, self.fc_total
         f = lambda *s: n.alloc(s, torch.float32)
         self.e, self.h1, self.a1, self.tm, self.st_ = f(N, hid), f(N, te), f(N, te), f(N, te), f(N, te)
         if self._skinny():      # 3 launches: embedding + Linear + SiLU, Linear + SiLU, the 22 projections
@@ -473,6 +478,7 @@ class _Temb:
 
     def bwd(self):
         n, st = self.net, self.net.store
+        assert not n.uniform_t, "a uniform_t plan is forward-only"
         N, hid, te, ft = n.N, self.hid, self.temb, self.fc_total
         f = lambda *s: n.alloc(s, torch.float32)
         d_st, d_tm, d_a1, d_h1 = f(N, te), f(N, te), f(N, te), f(N, te)
@@ -508,7 +514,10 @@ class UNet:
     `backward_plan` are `_lib.Recording`s that Trainer/Sampler splice into their own graphs."""
 
     def __init__(self, cfg, N, H, W, dtype=BF16, device=None, params=None, seed=1234, store=None, use_graph=True,
-                 group_wgrads=True, wgrad_group_bytes=None, pair_convs=True, f32_products="exact", _dry=False):
+                 group_wgrads=True, wgrad_group_bytes=None, pair_convs=True, f32_products="exact", uniform_t=False, _dry=False):
+        # uniform_t: the whole batch shares ONE timestep (the reverse sampler: sampler.py:137-145 passes a constant vector) -- the
+        # time-embedding MLP and its 22 projections then run on one row and every image reads projection row 0.  Forward-only.
+        self.uniform_t = bool(uniform_t)
         if _dry:       # shape/parameter bookkeeping only (no device, no kernels): see `param_table`
             self.cfg, self.N, self.H, self.W, self.dt = dict(cfg), N, H, W, dtype
             self.store = ParamStore()
@@ -562,8 +571,12 @@ class UNet:
             self.load_state_dict(params)
         self.forward_plan = self._record(self._emit_fwd)
         self.overwritten = set()         # gradient slots the backward STORES (filled in while it is recorded)
-        self.backward_plan = self._record(self._emit_bwd)
-        self._build_zero_table()
+        if self.uniform_t:
+            self.backward_plan = None    # forward-only plan
+            self.zero_table, self.zero_floats = None, 0
+        else:
+            self.backward_plan = self._record(self._emit_bwd)
+            self._build_zero_table()
         self._graph_fwd = None
 
     def _default_params(self, seed):
@@ -582,8 +595,20 @@ class UNet:
         plans = self.__dict__.setdefault("_batch_plans", {})
         if N not in plans:
             plans[N] = type(self)(self.cfg, N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store, use_graph=self.use_graph,
-                                  f32_products="split" if self.split_products else "exact")
+                                  f32_products="split" if self.split_products else "exact", uniform_t=self.uniform_t)
         return plans[N]
+
+    def with_uniform_t(self):
+        """The forward-only twin of this plan for a timestep shared by the whole batch (same weights, batch, dtype, products): what
+        `mdm.Sampler` runs -- the time-embedding path on one row instead of `sample_num` (0.125 -> ~0.04 ms of a 5.5 ms reverse step
+        at sample_num = 100)."""
+        if self.uniform_t:
+            return self
+        if getattr(self, "_uniform_twin", None) is None:
+            self._uniform_twin = type(self)(self.cfg, self.N, self.H, self.W, dtype=self.dt, device=self.device, store=self.store,
+                                            use_graph=self.use_graph, f32_products="split" if self.split_products else "exact", uniform_t=True)
+        self._uniform_twin.training = self.training
+        return self._uniform_twin
 
     def sampling_plan(self, N, precision="f32_split"):
         """The launch plan the reverse sampler should run on, with THIS model's current weights: `precision` =
@@ -841,7 +866,7 @@ class UNet:
         self.fc_w, self.fc_gw = st.P[e0.off:e0.off + ft * te].view(ft, te), st.G[e0.off:e0.off + ft * te].view(ft, te)
         self.fc_b, self.fc_gb = st.P[e1.off:e1.off + ft], st.G[e1.off:e1.off + ft]
         self.fc_weight_names = [nm + ".weight" for nm in names]
-        self.T_all = self.alloc((self.N, ft), torch.float32)
+        self.T_all = self.alloc((1 if self.uniform_t else self.N, ft), torch.float32)
         self.dT_all = self.alloc((self.N, ft), torch.float32)
         self.t_in = self.alloc((self.N,), torch.float32)
         cmax = max(a.C for a in self.acts)
@@ -994,12 +1019,17 @@ class UNet:
         time-embedding weights) are STORED by this pass, every other slot (biases, GroupNorm scales, ungrouped weights) is
         accumulated into and must have been cleared first (`emit_zero_grad`): two backward passes without an optimizer step
         in between do NOT add up -- gradient accumulation goes through TrainStep, which sums whole gradient buffers."""
+        if self.backward_plan is None:
+            raise RuntimeError("a uniform_t plan is forward-only")
         self.backward_plan.run()
 
     def forward(self, x, t):
         """x: [N,C,H,W] fp32 (any device), t: [N] -> object with `.sample` [N,C_out,H,W] fp32 on the GPU
         (reference contract: trainer_masked_mean_shift.py:140, sampler.py:145)."""
         assert tuple(x.shape) == (self.N, self.cin, self.H, self.W), (tuple(x.shape), (self.N, self.cin, self.H, self.W))
+        if self.uniform_t:
+            tt = t.reshape(-1)
+            assert bool((tt == tt[0]).all()), "this plan was built for ONE timestep per batch (uniform_t)"
         self.x_nchw.copy_(x.to(torch.float32), non_blocking=True)
         self.t_in.copy_(t.reshape(-1).to(torch.float32), non_blocking=True)
         ops.nchw_to_nhwc(self.dt, self.x_nchw, self.x_in.data, self.N, self.cin, self.H, self.W, self.cin_p)
