@@ -1248,9 +1248,8 @@ __device__ __forceinline__ void store8_pub(float* p, const float8& v) {
 
 template <int BM, int BN, int NW, int MI, int NI, typename T = bf16_t, bool WT = false>
 __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds, int m0, int n0, int row_w, int col_w,
-                                              int lane, int t, f32x4 (&acc)[MI][NI], const bool park = true) {
+                                              int lane, int t, f32x4 (&acc)[MI][NI]) {
     constexpr int PITCH = BN * 4;
-    if (park) {                      // (conv_halo_ws_body: only the multiplying waves hold accumulators; all NW waves store)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int ml = row_w + i * 16 + (lane & 15), m = m0 + ml;
@@ -1265,7 +1264,6 @@ __device__ __forceinline__ void epilogue_tile(const mdm_gemm_desc& d, char* lds,
             }
             *reinterpret_cast<float4*>(lds + ml * PITCH + (((nl >> 2) ^ (ml & 7)) << 4)) = v;
         }
-    }
     }
     __syncthreads();
     constexpr int CPR = BN / 8;
@@ -2767,19 +2765,6 @@ __device__ __forceinline__ void split_bf16_pair(f32x4& a, f32x4& b) {
 // channel slab is split ONCE, IN PLACE in LDS by all 512 threads during the last filter row of the slab in front of it (chunk g of a
 // 128-byte row becomes the 8 hi halves, chunk g ^ 4 the 8 lo halves of the same 8 channels: the fragment addresses do not change),
 // and the filter tiles arrive already split from the B_split shadow (mdm_split_shadow: same bytes, same arrangement).
-#ifndef MDM_HALO_LATE
-#define MDM_HALO_LATE 0
-#endif
-#ifdef MDM_H8_NOSPLIT
-#define MDM_H8_NOSPLIT_ 1
-#else
-#define MDM_H8_NOSPLIT_ 0
-#endif
-#ifdef MDM_H8_NODMA
-#define MDM_H8_LATE_OK 0
-#else
-#define MDM_H8_LATE_OK 1
-#endif
 template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf16_t, bool SPLIT = false, bool WT = false>
 __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx, const int m_base = 0) {
     static_assert(!SPLIT || sizeof(T) == 4, "conv_halo: SPLIT is the fp32-storage variant");
@@ -2948,14 +2933,6 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
 
     int a_cur = 0;                         // byte offset of the halo buffer being multiplied
     int b_stage = 0;                       // ring stage of the current tap-slab
-    // Waves w and w + 4 share a SIMD and leave every barrier together: both issuing their DMA pieces first (60 - 185 cycles of blocked
-    // issue per piece) leaves the matrix pipe idle meanwhile.  MDM_HALO_LATE: the upper four issue theirs behind the group's MFMAs
-    // (same operations in the same per-wave order, so the counted waits are unchanged; their tiles have D - 1 groups to land)
-#ifdef MDM_H8_NODMA
-    const bool dma_early = d.M < 0;                                     // timing only: no DMA issue inside the loop
-#else
-    const bool dma_early = !MDM_HALO_LATE || D < 2 || wave < 4;         // (D = 1: a tile issued late would be waited for at once)
-#endif
     const int a_flip = ABUF;               // the two halo buffers sit at offsets 0 and ABUF: a_cur toggles between them
 #define MDM_HALO_TAP(T)                                                                                          \
     {                                                                                                            \
@@ -2974,15 +2951,13 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
             const int rs = b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D;                                 \
             /* (dealing these DMA pieces out between the MFMAs of the tap, as conv_lin2 does, changed neither the  \
                bf16 step -- 3.904 vs 3.908 ms -- nor the fp32 sampler -- 14.38 vs 14.37 s: measured, not kept) */  \
-            if (dma_early) {                                                                                     \
             _Pragma("unroll") for (int k = 0; k < TG; ++k)                                                       \
                 issue_b((((T) / TG + D) % NG) * TG + k, cs + ((T) / TG + D) / NG, rs * STAGE_B + k * B_BYTES);   \
             _Pragma("unroll") for (int q = 0; q < APT; ++q)                                                      \
                 if (((T) / TG) * APT + q < NPW) issue_a(((T) / TG) * APT + q, cs + 1, lds + (a_cur ^ a_flip));   \
-            }                                                                                                    \
             if constexpr (SPLIT) {                                                                               \
                 MDM_T(const unsigned long long ts0 = stamp_now();)                                               \
-                if ((T) / TG == NG - 1 && cs + 1 < NCS && !MDM_H8_NOSPLIT_) split_halo(lds + (a_cur ^ a_flip));  \
+                if ((T) / TG == NG - 1 && cs + 1 < NCS) split_halo(lds + (a_cur ^ a_flip));                      \
                 MDM_T(t_split += stamp_now() - ts0;)                                                             \
             }                                                                                                    \
         }                                                                                                        \
@@ -3009,16 +2984,7 @@ __device__ __forceinline__ void conv_halo_body(const mdm_gemm_desc& d, char* lds
             halo_mma_split<MI, NI>(acc, bfr[1], afr[AF(T)][0]);                         /* b.lo x a.hi */       \
             halo_mma_split<MI, NI>(acc, bfr[0], afr[AF(T)][0]);                         /* b.hi x a.hi */       \
         } else halo_mma_tile<MI, NI>(acc, bfr[1], afr[AF(T)][1]);                                                \
-        if ((T) % TG == TG - 1) {                                                                                \
-            if (!dma_early && MDM_H8_LATE_OK) { /* the second wave of a SIMD issues its pieces BEHIND the group's MFMAs */ \
-                const int rs = b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D;                             \
-                _Pragma("unroll") for (int k = 0; k < TG; ++k)                                                   \
-                    issue_b((((T) / TG + D) % NG) * TG + k, cs + ((T) / TG + D) / NG, rs * STAGE_B + k * B_BYTES); \
-                _Pragma("unroll") for (int q = 0; q < APT; ++q)                                                  \
-                    if (((T) / TG) * APT + q < NPW) issue_a(((T) / TG) * APT + q, cs + 1, lds + (a_cur ^ a_flip)); \
-            }                                                                                                    \
-            b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                                      \
-        }                                                                                                        \
+        if ((T) % TG == TG - 1) b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                  \
     }
 #define AF(T) (A_TABLE ? ((T) & 1) : 0)
     Frag afr[A_TABLE ? 2 : 1][2][MI];      // [tap parity][k-step][fragment]: tap T multiplies set T&1 while set (T+1)&1 is fetched
@@ -3058,305 +3024,6 @@ template <int BM, int NPW, int BN = 64, int NSB = 4, int TG = 1, typename T = bf
 __global__ __launch_bounds__(512) void conv_halo_kernel(mdm_gemm_desc d) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     conv_halo_body<BM, NPW, BN, NSB, TG, T, SPLIT>(d, lds, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// ----------------------------------------------------------------------------
-// conv_halo_ws: the big-map tile of conv_halo_body with the waves SPECIALISED ("one wave per SIMD on the matrix pipe").
-// What the measurements of round 4 said about the 256 x 128 split tile (sample_num = 100, 256+256 -> 256 at 16x16, 144 taps):
-//   eight equal waves (conv_halo_body)            152 us: 2 050 cycles per tap against 1 536 of MFMA issue; without its DMA issue 144,
-//                                                 without DMA issue and halo split 134 (1 730 per tap)
-//   four waves, one per SIMD, doing everything    160 us: 2 100 per tap; without DMA issue 134, without DMA issue and split 124 (1 590
-//   (8 x 4 accumulators, fragments of the next    per tap: the matrix pipe's own time) -- an LDS-DMA piece blocks the issuing wave ~70
-//   block read between this block's MFMAs)        cycles (MI355X_MICROARCH.md price list: 60 - 185) and with one wave per SIMD nothing
-//                                                 else feeds the matrix pipe meanwhile: 5.3 pieces per tap and wave = 380 cycles.
-//                                                 Leaving the barriers 16 / 32 / 64 cycles apart per wave only added the skew (+6 / +14 /
-//                                                 +37 %): the price is the issuing wave's own, not a queue the four waves share.
-// Hence: waves 0 .. 3 (one per SIMD) multiply and do nothing else -- a 128 x 64 block of the tile each, 8 x 4 accumulators, per 16
-// pixels two halo fragments for 12 (split) / 8 (bf16) MFMAs, the next 16 pixels' fragments and one of the next tap's eight filter
-// fragments read in their shadow; waves 4 .. 7 (the second wave of every SIMD) issue every LDS-DMA piece, wait for them (counted
-// vmcnt) and split the next halo in place (SPLIT).  Both kinds meet at ONE barrier per tap:
-//   barrier of tap T: the filter tile of tap T+1 and (tap 8) the split halo of the next channel slab are in LDS; every multiplying wave
-//   is done with tile T-1 (its stage takes tile T+3) and, at tap 0, with the previous halo buffer.
-// Both kinds must fit the 256 registers two waves per SIMD leave each: the multiplying waves keep 128 accumulator + 16 + 64 fragment
-// registers and compute their fragment addresses (no 9 x 8 table).  Same LDS layout, swizzles, descriptors and epilogue as
-// conv_halo_body; requires N % BN == 0 and what halo_tile requires.
-// ----------------------------------------------------------------------------
-#ifdef MDM_WS_NODMA               // timing-only switches (wrong results)
-#define MDM_WS_NODMA_ 1
-#else
-#define MDM_WS_NODMA_ 0
-#endif
-#ifdef MDM_WS_NOSPLIT
-#define MDM_WS_NOSPLIT_ 1
-#else
-#define MDM_WS_NOSPLIT_ 0
-#endif
-template <int BM, int BN, int NPW, typename T = bf16_t, bool SPLIT = false>
-__device__ __forceinline__ void conv_halo_ws_body(const mdm_gemm_desc& d, char* lds, const int bx, const int gx) {
-    static_assert(!SPLIT || sizeof(T) == 4, "conv_halo_ws: SPLIT is the fp32-storage variant");
-    static_assert(SPLIT || sizeof(T) == 2, "conv_halo_ws: bf16, or fp32 storage with split products");
-    constexpr int NC = 4, NP = 4, NW = NC + NP;                      // multiplying waves, loading waves
-    constexpr int WR = 2, WC = 2, WM = BM / WR, WN = BN / WC, MI = WM / 16, NI = WN / 16;
-    static_assert(MI % 2 == 0 && NI <= MI, "conv_halo_ws: fragment schedule");
-    constexpr int NSB = 4, D = 3;                                   // filter stages, refill distance in taps
-    constexpr int KC = 128 / (int)sizeof(T);                        // channels per slab (one 128-byte halo row)
-    constexpr int B_BYTES = BN * 128, GBW = BN / (8 * NP);          // one tap's filter tile; its 1-KiB pieces per loading wave
-    static_assert(BN % (8 * NP) == 0, "conv_halo_ws: filter pieces per wave");
-    constexpr int NHT = 4, APT = (NPW + NHT - 1) / NHT;             // the next slab's halo pieces go out in taps 0 .. NHT-1, APT per tap
-    constexpr int ABUF = NP * NPW * 1024;
-    MDM_T(const unsigned long long t_entry = stamp_now();)
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int OW = d.OW, OH = d.OH, HW2 = OW + 2;
-    const int ow_sh = __builtin_ctz(OW), p_sh = ow_sh + __builtin_ctz(OH);
-    const int R = BM >> ow_sh;                                      // image rows of the tile (BM <= OH * OW)
-    const int HR = (R + 2) * HW2, NPA = (HR + 7) >> 3;
-    char* const bring = lds + 2 * ABUF;
-    char* const dummy = bring + NSB * B_BYTES;
-    const int tiles_n = d.N / BN;
-    const int bid = xcd_remap(bx, gx);
-    const int mt = udiv_small(bid, tiles_n), n0 = (bid - mt * tiles_n) * BN, m0 = mt * BM;
-    const int NCS = d.Ck / KC;
-    const int wr = (wave & 3) / WC, wc = (wave & 3) % WC;
-    f32x4 acc[MI][NI];
-    MDM_T(unsigned long long t_wait = 0, t_bar = 0, t_split = 0, tstart = 0, t_loop_end = 0;)
-
-    if (wave >= NC) {
-        // ================================================= the loading waves =================================================
-        const int pw = wave - NC, tp = t - NC * 64;
-        const int img = m0 >> p_sh, y0 = (m0 >> ow_sh) & (OH - 1);
-        const float inv_hw2 = __builtin_amdgcn_rcpf((float)HW2);
-        const char* zlane = reinterpret_cast<const char*>(g_zero_page) + lane * 16;
-        // halo pieces of this wave: piece p = pw + 4 k holds halo rows 8p .. 8p+7
-        int apix[NPW];
-        const int lch16 = ((lane & 7) ^ (lane >> 3)) << 4;
-#pragma unroll
-        for (int k = 0; k < NPW; ++k) {
-            const int hr = (pw + NP * k) * 8 + (lane >> 3);
-            const int hy = (int)(((float)hr + 0.5f) * inv_hw2), hx = hr - hy * HW2;
-            const int y = y0 - 1 + hy, x = hx - 1;
-            const bool ok = hr < HR && (unsigned)y < (unsigned)OH && (unsigned)x < (unsigned)OW && m0 < d.M;
-            apix[k] = ok ? ((img * (OH >> d.ups) + (y >> d.ups)) * (OW >> d.ups) + (x >> d.ups)) : -1;
-        }
-        auto issue_a = [&](int k, int cs, char* abuf) {             // k compile-time after unrolling; k >= NPW: a dummy (uniform counts)
-            const int kk = k < NPW ? k : 0;
-            const int p = pw + NP * kk;
-            const int c = cs * KC;
-            const bool s1 = c >= d.C0;
-            const T* S = reinterpret_cast<const T*>(s1 ? d.src1 : d.src0);
-            const int ld = s1 ? d.ld1 : d.ld0, cc = s1 ? c - d.C0 : c;
-            const char* src = reinterpret_cast<const char*>(S + (int64_t)apix[kk] * ld + cc) + lch16;
-            lds_dma16((k < NPW && apix[kk] >= 0 && cs < NCS) ? src : zlane, (k < NPW && p < NPA) ? abuf + p * 1024 : dummy);
-        };
-        // filter tile of (tap, slab): BN rows x 128 B; piece q of this wave = rows 32 q + 8 pw ..
-        const int bn = n0 + pw * 8 + (lane >> 3);
-        const char* b_row = reinterpret_cast<const char*>(reinterpret_cast<const T*>(SPLIT ? d.B_split : d.B) + (int64_t)bn * d.ldb) + lch16;
-        auto issue_b = [&](int tap, int cs, int stage) {
-            const int64_t off = ((int64_t)tap * d.wtap + (int64_t)cs * KC) * (int64_t)sizeof(T);
-#pragma unroll
-            for (int q = 0; q < GBW; ++q)
-                lds_dma16(cs < NCS ? b_row + off + (int64_t)q * (8 * NP) * d.ldb * (int64_t)sizeof(T) : zlane,
-                          bring + stage * B_BYTES + (pw + NP * q) * 1024);
-        };
-        // SPLIT: halo rows [0, HR) of `abuf` from fp32 to (hi, lo) bf16 halves in place (conv_halo_body's split_halo on 256 threads);
-        // part 0 / 1 of 2: the even / odd pairs of items of a thread.  The loading waves share their SIMDs' vector issue with the MFMAs
-        // (8 of every 16 cycles are the MFMA's): the whole pass behind one barrier took longer than a tap and the multiplying waves waited
-        // for it at the next one (149 -> 136 us without the pass); in two parts behind the barriers of taps 6 and 7 it fits.
-        auto split_halo = [&](char* abuf, int part, int nparts) {
-            auto slot = [&](int id, bool second) {
-                const int hr = id >> 2, pg = ((id & 3) ^ hr) & 7;
-                return reinterpret_cast<f32x4*>(abuf + hr * 128 + ((second ? pg ^ 4 : pg) << 4));
-            };
-            for (int id = tp + part * 2 * NP * 64; id < HR * 4; id += nparts * 2 * NP * 64) {
-                const int id1 = id + NP * 64;
-                f32x4 *pa0 = slot(id, false), *pb0 = slot(id, true);
-                f32x4 va0 = *pa0, vb0 = *pb0;
-                if (id1 < HR * 4) {
-                    f32x4 *pa1 = slot(id1, false), *pb1 = slot(id1, true);
-                    f32x4 va1 = *pa1, vb1 = *pb1;
-                    split_bf16_pair(va0, vb0);
-                    *pa0 = va0; *pb0 = vb0;
-                    split_bf16_pair(va1, vb1);
-                    *pa1 = va1; *pb1 = vb1;
-                } else {
-                    split_bf16_pair(va0, vb0);
-                    *pa0 = va0; *pb0 = vb0;
-                }
-            }
-        };
-#pragma unroll
-        for (int k = 0; k < NPW; ++k) issue_a(k, 0, lds);
-#pragma unroll
-        for (int u = 0; u < D; ++u) issue_b(u, 0, u);
-        wait_vmcnt<D * GBW>();
-        __builtin_amdgcn_s_barrier();                               // (1) the halo of slab 0 is in LDS
-        if constexpr (SPLIT) {
-            split_halo(lds, 0, 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        wait_vmcnt<(D - 1) * GBW>();
-        __builtin_amdgcn_s_barrier();                               // (2) ... split, and the filter tile of tap 0 as well
-        int b_stage = 0;
-        MDM_T(tstart = stamp_now();)
-#define MDM_WS_LOAD_TAP(T)                                                                                           \
-        {                                                                                                            \
-            MDM_T(const unsigned long long tw0 = stamp_now();)                                                       \
-            wait_vmcnt<((((T) + 7) % 9) < NHT ? APT : 0) + GBW + ((((T) + 8) % 9) < NHT ? APT : 0)>();               \
-            MDM_T(const unsigned long long tw1 = stamp_now(); t_wait += tw1 - tw0;)                                  \
-            __builtin_amdgcn_s_barrier();                                                                            \
-            MDM_T(t_bar += stamp_now() - tw1;)                                                                       \
-            if (!MDM_WS_NODMA_) {                                                                                    \
-            issue_b(((T) + D) % 9, cs + ((T) + D) / 9, b_stage + D >= NSB ? b_stage + D - NSB : b_stage + D);        \
-            if ((T) < NHT) { _Pragma("unroll") for (int q = 0; q < APT; ++q) issue_a((T) * APT + q, cs + 1, anext); } \
-            }                                                                                                        \
-            /* (the halo pieces went out behind the barriers of taps 0 .. 3: at the barrier of tap 6 every loading wave has  \
-               waited for its own -- they are older than tile 7, issued at tap 4) */                                 \
-            if (SPLIT && ((T) == 6 || (T) == 7) && cs + 1 < NCS && !MDM_WS_NOSPLIT_) {                               \
-                MDM_T(const unsigned long long ts0 = stamp_now();)                                                   \
-                split_halo(anext, (T) - 6, 2);                                                                       \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
-                MDM_T(t_split += stamp_now() - ts0;)                                                                 \
-            }                                                                                                        \
-            b_stage = b_stage + 1 == NSB ? 0 : b_stage + 1;                                                          \
-        }
-        for (int cs = 0; cs < NCS; ++cs) {
-            char* const anext = lds + ((cs + 1) & 1) * ABUF;
-            MDM_WS_LOAD_TAP(0) MDM_WS_LOAD_TAP(1) MDM_WS_LOAD_TAP(2) MDM_WS_LOAD_TAP(3) MDM_WS_LOAD_TAP(4)
-            MDM_WS_LOAD_TAP(5) MDM_WS_LOAD_TAP(6) MDM_WS_LOAD_TAP(7) MDM_WS_LOAD_TAP(8)
-        }
-#undef MDM_WS_LOAD_TAP
-        wait_vmcnt<0>();
-        MDM_T(t_loop_end = stamp_now();)
-    } else {
-        // ================================================ the multiplying waves ================================================
-        const int sgn = d.transposed ? -1 : 1;
-        const int lane_g = lane >> 4;
-        int a_hb[MI], b_off[NI];                                    // centre-tap halo row of this lane's pixel in each 16-row block; filter rows
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int ml = wr * WM + i * 16 + (lane & 15);
-            const int r = ml >> ow_sh, x = ml - (r << ow_sh);
-            a_hb[i] = (r + 1) * HW2 + x + 1;
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int nl = wc * WN + j * 16 + (lane & 15);
-            b_off[j] = nl * 128 + ((lane_g ^ (nl & 7)) << 4);
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto rd = [&](const char* p) { return *reinterpret_cast<const bf16x8*>(p); };
-        int zs = 0;
-        int hw2s = sgn * HW2;                                       // (made opaque once per tap: hipcc otherwise hoists all 72 fragment
-                                                                    // addresses out of the slab loop and spills them)
-        auto a_at = [&](int tp, int i) -> int {                     // tp, i compile-time after unrolling
-            const int ty = tp / 3, tx = tp - ty * 3;
-            const int hr = a_hb[i] + zs + (ty - 1) * hw2s + sgn * (tx - 1);
-            return hr * 128 + ((lane_g ^ (hr & 7)) << 4);
-        };
-        // fragments: [0] = the low 64 bytes of a 128-byte row (bf16: k-step 0; SPLIT: hi halves), [1] = the high 64 (k-step 1; lo halves)
-        bf16x8 fa[2][2], fb[2][NI], fbn[NI];                        // fa[pixel-block parity][half]
-        __builtin_amdgcn_s_barrier();                               // (1)
-        __builtin_amdgcn_s_barrier();                               // (2)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) { fb[0][j] = rd(bring + b_off[j]); fb[1][j] = rd(bring + (b_off[j] ^ 64)); }
-        { const int a0 = a_at(0, 0); fa[0][0] = rd(lds + a0); fa[0][1] = rd(lds + (a0 ^ 64)); }
-        int an_pipe = a_at(0, 1);                                   // address of the fragments the NEXT block reads
-        int b_stage = 0;
-        MDM_T(tstart = stamp_now();)
-        // one block of 16 pixels: its products into acc[i][*]; in their shadow the next block's two halo fragments and one of the next
-        // tap's filter fragments: the first halves (b.hi / k-step 0) go to a spare set over blocks 0 .. NI-1, the second halves straight
-        // into fb[1] in the LAST block, behind the product that reads fb[1] for the last time (a second spare set did not fit: 256
-        // registers per wave with two waves per SIMD -- the first version spilled ~20 registers per tap)
-#define MDM_WS_MMA(BH, AH)                                                                                           \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                           \
-                acc[I_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[BH][j], fa[I_ & 1][AH], acc[I_][j], 0, 0, 0);
-#define MDM_WS_MUL_BLOCK(T, I)                                                                                       \
-        {                                                                                                            \
-            constexpr int I_ = (I), IN_ = (I_ + 1) % MI;                                                             \
-            constexpr int T2_ = I_ + 2 < MI ? (T) : ((T) + 1) % 9, I2_ = (I_ + 2) % MI;     /* the block after the next */ \
-            constexpr bool LAST_ = I_ == MI - 1;                                                                     \
-            const char* const An_ = (I_ + 1 < MI || (T) < 8) ? acur : anext;                                         \
-            const int an_ = an_pipe;                      /* computed one block ahead, between the MFMAs of that block */ \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-            fa[IN_ & 1][0] = rd(An_ + an_);                                                                          \
-            if (I_ < NI) fbn[I_] = rd(Bn + b_off[I_]);                                                               \
-            if constexpr (SPLIT) { MDM_WS_MMA(1, 0) }                                      /* b.lo x a.hi */         \
-            else { MDM_WS_MMA(1, 1) }                                                      /* k-step 1 */            \
-            an_pipe = a_at(T2_, I2_);                                                                                \
-            if (LAST_) { _Pragma("unroll") for (int j = 0; j < NI; ++j) fb[1][j] = rd(Bn + (b_off[j] ^ 64)); }       \
-            if constexpr (SPLIT) { MDM_WS_MMA(0, 1) }                                      /* b.hi x a.lo */         \
-            fa[IN_ & 1][1] = rd(An_ + (an_ ^ 64));                                                                   \
-            MDM_WS_MMA(0, 0)                                                               /* b.hi x a.hi; k-step 0 */ \
-            /* pinned order: read(s), NI x (MFMA, 2 VALU), [last block: NI x (read, MFMA)], read, NI MFMAs: an MFMA leaves the   \
-               vector issue free for two VALU instructions, a run of ten between two MFMAs costs 30 cycles of the matrix pipe */ \
-            __builtin_amdgcn_sched_group_barrier(0x100, I_ < NI ? 2 : 1, 0);                                         \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                         \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                   \
-            }                                                                                                        \
-            if (LAST_) {                                                                                             \
-                _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                     \
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
-                    if (SPLIT) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                               \
-                }                                                                                                    \
-            } else if (SPLIT) {                                                                                      \
-                _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                     \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                               \
-                }                                                                                                    \
-            }                                                                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
-            __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-        }
-#define MDM_WS_MUL_TAP(T)                                                                                            \
-        {                                                                                                            \
-            const int sn = b_stage + 1 == NSB ? 0 : b_stage + 1;                                                     \
-            const char* const Bn = bring + sn * B_BYTES;                                                             \
-            asm volatile("" : "+s"(hw2s), "+s"(zs));                                                                 \
-            MDM_T(const unsigned long long tw1 = stamp_now();)                                                       \
-            __builtin_amdgcn_s_barrier();                                                                            \
-            MDM_T(t_bar += stamp_now() - tw1;)                                                                       \
-            MDM_WS_MUL_BLOCK(T, 0) MDM_WS_MUL_BLOCK(T, 1) MDM_WS_MUL_BLOCK(T, 2) MDM_WS_MUL_BLOCK(T, 3)              \
-            MDM_WS_MUL_BLOCK(T, 4) MDM_WS_MUL_BLOCK(T, 5) MDM_WS_MUL_BLOCK(T, 6) MDM_WS_MUL_BLOCK(T, 7)              \
-            _Pragma("unroll") for (int j = 0; j < NI; ++j) fb[0][j] = fbn[j];                                        \
-            b_stage = sn;                                                                                            \
-        }
-        static_assert(MI == 8, "conv_halo_ws: eight pixel blocks per multiplying wave");
-        for (int cs = 0; cs < NCS; ++cs) {
-            const char* const acur = lds + (cs & 1) * ABUF;
-            const char* const anext = lds + ((cs + 1) & 1) * ABUF;
-            MDM_WS_MUL_TAP(0) MDM_WS_MUL_TAP(1) MDM_WS_MUL_TAP(2) MDM_WS_MUL_TAP(3) MDM_WS_MUL_TAP(4)
-            MDM_WS_MUL_TAP(5) MDM_WS_MUL_TAP(6) MDM_WS_MUL_TAP(7) MDM_WS_MUL_TAP(8)
-        }
-#undef MDM_WS_MUL_TAP
-#undef MDM_WS_MUL_BLOCK
-#undef MDM_WS_MMA
-        MDM_T(t_loop_end = stamp_now();)
-    }
-    __syncthreads();
-    epilogue_tile<BM, BN, NW, MI, NI, T, false>(d, lds, m0, n0, wr * WM, wc * WN, lane, t, acc, wave < NC);
-#ifdef MDM_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
-        const unsigned widx = (unsigned)bx * NW + wave;
-        if (widx < 4096) {
-            unsigned long long* r = g_stamp_buf + widx * 32;
-            r[0] = t_wait; r[1] = t_bar; r[2] = t_split; r[3] = 0; r[4] = NCS * 9; r[5] = 1; r[6] = t_loop_end - tstart; r[7] = tstart;
-            r[8] = tstart - t_entry; r[9] = stamp_now() - t_loop_end; r[10] = t_entry;
-        }
-    }
-#endif
-}
-
-template <int BM, int BN, int NPW, typename T = bf16_t, bool SPLIT = false>
-__global__ __launch_bounds__(512) void conv_halo_ws_kernel(mdm_gemm_desc d) {
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    conv_halo_ws_body<BM, BN, NPW, T, SPLIT>(d, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 
@@ -4042,26 +3709,6 @@ static int launch_halo(const mdm_gemm_desc& d, hipStream_t s) {      // TG = 3: 
     hipLaunchKernelGGL((conv_halo_kernel<BM, NPW, BN, NSB, TG, T, SPLIT>), grid, dim3(512), bytes, s, d);
     return 0;
 }
-#ifndef MDM_HALO_WS
-#define MDM_HALO_WS 1               // 0: the tiles of eight equal waves everywhere (A/B builds)
-#endif
-template <int BM, int BN, int NPW, typename T = bf16_t, bool SPLIT = false>
-static int launch_halo_ws(const mdm_gemm_desc& d, hipStream_t s) {    // conv_halo_ws_body: four multiplying + four loading waves
-    const int NPA = halo_pieces(BM, d.OH, d.OW);
-    int bytes = 2 * 4 * NPW * 1024 + 4 * BN * 128 + 1024;
-    if (bytes < BM * BN * 4) bytes = BM * BN * 4;                 // the tile epilogue parks the fp32 tile there
-    MDM_REQUIRE(NPA <= 4 * NPW && bytes <= 160 * 1024 && d.N % BN == 0 && d.M % BM == 0 && BM <= d.OH * d.OW,
-                "conv_halo_ws: tile does not fit (NPA=%d, %d bytes, N=%d)", NPA, bytes, d.N);
-    static int configured = 0;
-    if (configured < bytes) {
-        MDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_ws_kernel<BM, BN, NPW, T, SPLIT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        configured = bytes;
-    }
-    dim3 grid((unsigned)((int64_t)(d.M / BM) * (d.N / BN)));
-    hipLaunchKernelGGL((conv_halo_ws_kernel<BM, BN, NPW, T, SPLIT>), grid, dim3(512), bytes, s, d);
-    return 0;
-}
 static int small_pieces(const mdm_gemm_desc& d, int bm = 64) {           // 1-KiB pieces of one conv_small halo buffer (256-byte pixel rows)
     const int imgs = bm / (d.OH * d.OW);
     return (imgs * (d.OH + 2) * (d.OW + 2) + 3) / 4;
@@ -4463,8 +4110,7 @@ static int gemm_launch(const mdm_gemm_desc* dh, hipStream_t s) {
             // 12 for 24; half as many tiles, so a 16x16 layer at sample_num = 100 is ONE round of workgroups instead of 1.56 in two
             if (hb32 == 256 && MDM_SPLIT_BN128 && d.N % 128 == 0 && (d.OW == 16 || d.OW == 32) &&
                 (int64_t)(d.M / 256) * (d.N / 128) >= MDM_SPLIT_BN128) {
-                if (MDM_HALO_WS && halo_pieces(256, d.OH, d.OW) <= 44) rc = launch_halo_ws<256, 128, 11, float, true>(d, s);
-                else rc = npw <= 4 ? launch_halo<256, 4, 4, 128, float, true, 1>(d, s) : launch_halo<256, 6, 4, 128, float, true, 1>(d, s);
+                rc = npw <= 4 ? launch_halo<256, 4, 4, 128, float, true, 1>(d, s) : launch_halo<256, 6, 4, 128, float, true, 1>(d, s);
             } else
             if (hb32 == 256 && (rc = launch_halo_mixed(d, s)) != -2) { /* whole rounds of 256-pixel tiles + a short round of 128-pixel ones */ }
             else if (hb32 == 256) rc = npw <= 4 ? launch_halo<256, 4, MDM_SPLIT_NSB256, 64, float, true>(d, s) : launch_halo<256, 6, MDM_SPLIT_NSB256, 64, float, true>(d, s);
