@@ -13,7 +13,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 dt = 1 if mode == "bf16" else 0
 tdt = torch.bfloat16 if mode == "bf16" else torch.float32
-LAYERS = [(128, 0, 128, 32, 0), (128, 128, 128, 32, 0), (256, 0, 256, 16, 0), (256, 256, 256, 16, 0), (256, 0, 256, 16, 1), (256, 0, 256, 8, 0), (512, 0, 512, 4, 0)]
+LAYERS = [(128, 0, 128, 32, 0), (128, 128, 128, 32, 0), (256, 0, 256, 16, 0), (256, 256, 256, 16, 0), (256, 0, 256, 16, 1), (256, 0, 256, 8, 0), (256, 256, 256, 8, 0),
+          (256, 0, 256, 4, 0), (256, 256, 256, 4, 0), (256, 0, 256, 4, 1)]      # unet6 at 32x32: 128 / 256 / 256 / 256 channels
 tot = 0.0
 for (c0, c1, co, H, ups) in LAYERS:
     g = ops.ConvGeom(N=N, IH=H, IW=H, C0=c0, C1=c1, Cout=co, ups=ups)
