@@ -38,8 +38,68 @@ __device__ __forceinline__ float gn_pivot(const T* s0, const T* s1, int C0, int 
 // v = t % VB (its 8-channel vector) and the sums run over the 256/VB pixel lanes of each column.
 // (The first version reduced with __shfl_xor: 4 ds_bpermute round trips per value, 128 per thread in the
 // backward -- 20k cycles of a 36k-cycle kernel.)  scratch: K * CS_PITCH floats; out[k * VB + v].
+#ifndef MDM_GN_COLSUM_SHFL
+#define MDM_GN_COLSUM_SHFL 1        // 0: every column sum through LDS (A/B builds)
+#endif
+// Column sums inside the wave by RECURSIVE HALVING (VB a power of two: the lanes of a column are those with equal low log2(VB) bits):
+// at the step over lane bit b a lane keeps one half of the quantities it still holds (the upper half where its bit is set), sends the
+// other half to its partner and adds what the partner sends -- K/2 + K/4 + ... <= K - 1 ds_bpermute per lane for ALL K quantities
+// (the plain butterfly of the first version needed log2(lanes) per quantity: 128 in the backward), after which lane l holds quantity
+// q0(l) (+ r, r < K >> steps) summed over its column's lanes of this wave.  Those K * VB values per wave go to LDS ([wave][k][v]) and
+// K * VB threads add the waves up in ascending order.  LDS traffic: NT/64 * K * VB floats instead of K * NT.
+template <int K, int S>
+__device__ __forceinline__ void colsum_halving_step(float (&cur)[K], int& q0, int l, int vsh) {
+    const int bitpos = vsh + S;
+    if (bitpos < 6) {                                                 // uniform
+        const int mask = 1 << bitpos;
+        const bool up = (l >> bitpos) & 1;
+        constexpr int n = (K >> S) > 1 ? (K >> S) : 1;                // quantities a lane holds in front of step S
+        if constexpr (n > 1) {
+            constexpr int half = n / 2;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const float send = up ? cur[j] : cur[half + j];
+                const float keep = up ? cur[half + j] : cur[j];
+                cur[j] = keep + __shfl_xor(send, mask, 64);
+            }
+            q0 += up ? half : 0;
+        } else {
+            cur[0] += __shfl_xor(cur[0], mask, 64);
+        }
+    }
+}
+template <int K, int NT = 256>
+__device__ __forceinline__ void block_colsum_shfl(const float (&val)[K], float* scratch, float* out, int t, int VB) {
+    static_assert((K & (K - 1)) == 0 && K >= 8, "block_colsum_shfl: K a power of two");
+    const int l = t & 63, w = t >> 6, v = l & (VB - 1);
+    const int vsh = __builtin_ctz(VB);                               // uniform
+    float cur[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cur[k] = val[k];
+    int q0 = 0;
+    colsum_halving_step<K, 0>(cur, q0, l, vsh); colsum_halving_step<K, 1>(cur, q0, l, vsh); colsum_halving_step<K, 2>(cur, q0, l, vsh);
+    colsum_halving_step<K, 3>(cur, q0, l, vsh); colsum_halving_step<K, 4>(cur, q0, l, vsh); colsum_halving_step<K, 5>(cur, q0, l, vsh);
+    const int steps = 6 - vsh;
+    const int R = (K >> steps) > 1 ? (K >> steps) : 1;               // quantities left per lane (K >> steps == 0: duplicates, same value)
+    constexpr int RMAX = (K >> 3) > 1 ? (K >> 3) : 1;                // VB <= 8
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+        if (r < R) scratch[(w * K + q0 + r) * VB + v] = cur[r];
+    __syncthreads();
+    if (t < K * VB) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NT / 64; ++ww) sum += scratch[ww * K * VB + t];
+        out[t] = sum;
+    }
+    __syncthreads();
+}
 template <int K, int NT = 256>
 __device__ __forceinline__ void block_colsum(const float (&val)[K], float* scratch, float* out, int t, int VB, int PL) {
+    if (MDM_GN_COLSUM_SHFL && (VB & (VB - 1)) == 0 && VB <= 8) {     // uniform
+        block_colsum_shfl<K, NT>(val, scratch, out, t, VB);
+        return;
+    }
     constexpr int CS_PITCH = NT + 4;
 #pragma unroll
     for (int k = 0; k < K; ++k) scratch[k * CS_PITCH + t] = val[k];
