@@ -94,9 +94,11 @@ __device__ __forceinline__ void block_colsum_shfl(const float (&val)[K], float* 
     }
     __syncthreads();
 }
-template <int K, int NT = 256>
+// SHFL: the bf16 kernels (measured: step 3.528 -> 3.502 ms); the fp32-storage forward of the reverse sampler keeps the LDS sums (its
+// lanes hold 8 NP fp32 registers of the slice: with the halving's K more the sampler read 5.36 - 5.47 against 5.33 ms per reverse step)
+template <int K, int NT = 256, bool SHFL = true>
 __device__ __forceinline__ void block_colsum(const float (&val)[K], float* scratch, float* out, int t, int VB, int PL) {
-    if (MDM_GN_COLSUM_SHFL && (VB & (VB - 1)) == 0 && VB <= 8) {     // uniform
+    if (MDM_GN_COLSUM_SHFL && SHFL && (VB & (VB - 1)) == 0 && VB <= 8) {     // uniform
         block_colsum_shfl<K, NT>(val, scratch, out, t, VB);
         return;
     }
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_reg_kernel(const T* s0, int C0, con
         }
     }
     if (MODE != 2) {
-        block_colsum<16, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
+        block_colsum<16, NT, sizeof(T) == 2>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v]
         // one thread per group walks its channels in order (it was an LDS float atomic per channel: arrival order)
         if (t < ng) {
             float gv[2];
