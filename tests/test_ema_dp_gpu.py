@@ -78,8 +78,10 @@ def test_ema_shadow_vs_oracle(dt):
     med = sorted(rms.values())[len(rms) // 2]
     keys = [k for k in rms if rms[k] > 1e-3 * med]
     assert len(keys) > 0.8 * len(rms)
-    # measured (profiles/r04_parity_notes.jsonl): fp32 rel 5.3e-5, worst fraction 2.5e-4; bf16 rel 2.2e-3, 3.3e-4 -- bars at <= 3x
-    tol_el, tol_frac, tol_rel = (3e-5, 8e-4, 1.6e-4) if dt == 0 else (2.5e-3, 1e-3, 7e-3)
+    # measured (profiles/r04_parity_notes.jsonl): fp32 rel 5.3e-5, worst fraction 2.5e-4; bf16 rel 2.2e-3, worst fraction 3.3e-4 ... 1.2e-3
+    # over builds that differ only in the summation order of the GroupNorm column sums (the bf16 path's gradients are rounding noise
+    # on the 8-channel first convolution, and AdamW turns a flipped sign into +-lr) -- bars at <= 3x the largest
+    tol_el, tol_frac, tol_rel = (3e-5, 8e-4, 1.6e-4) if dt == 0 else (2.5e-3, 3e-3, 7e-3)
     worst = 0.0
     for k, e in zip(ref.keys, ema_ref):
         if k not in keys:
