@@ -19,6 +19,19 @@ namespace mdm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef MDM_STAMP
+__device__ unsigned long long g_tstamp_buf[1024 * 8];
+__device__ __forceinline__ unsigned long long tstamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MDM_TT(...) __VA_ARGS__
+#else
+#define MDM_TT(...)
+#endif
 __device__ __forceinline__ float silu_grad(float v) {
     const float s = 1.f / (1.f + expf(-v));
     return s * (1.f + v * (1.f - s));
@@ -63,6 +76,7 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16 * NB, kq = K >> 2, kbeg = wave * kq;
     const int r16 = lane & 15, kg = 4 * (lane >> 4);
+    MDM_TT(const unsigned long long ts0 = tstamp_now(); unsigned long long ts1 = 0, ts2 = 0;)
     f32x4 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -83,10 +97,16 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict_
         for (int u = 0; u < DEPTH; ++u) {
             const int k = kb + 16 * u + kg;
             const bool live = kb + 16 * u < kbeg + kq;
+            // (loads from a CLAMPED address, the value zeroed afterwards: `cond ? *p : zero4` made hipcc select between the global
+            // pointer and a private zero constant, i.e. 4 flat_load_dword per float4 with a scratch store in front -- the load phase of
+            // these kernels was 24 000 - 33 000 cycles of a 13 - 18 us launch, scripts/stamp_temb.py)
+            const int ks = live ? k : kbeg + kg;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int n = n0 + j * 16 + r16;
-                b[u][j] = (live && n < N) ? *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + k) : zero4;
+                const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)(n < N ? n : N - 1) * ldw + ks);
+                const bool ok = live && n < N;
+                b[u][j] = make_float4(ok ? w.x : 0.f, ok ? w.y : 0.f, ok ? w.z : 0.f, ok ? w.w : 0.f);
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
@@ -100,10 +120,13 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict_
                         if (emb_out && blockIdx.x == 0) *reinterpret_cast<float4*>(emb_out + (int64_t)m * K + k) = a[u][i];
                     }
                 } else {
-                    a[u][i] = (live && m < M) ? *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k) : zero4;
+                    const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(m < M ? m : M - 1) * ldx + ks);
+                    const bool ok = live && m < M;
+                    a[u][i] = make_float4(ok ? xv.x : 0.f, ok ? xv.y : 0.f, ok ? xv.z : 0.f, ok ? xv.w : 0.f);
                 }
             }
         }
+        MDM_TT(ts1 = tstamp_now();)
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
@@ -117,8 +140,11 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][j].w, a[u][i].w, acc[i][j], 0, 0, 0);
                 }
     }
+    MDM_TT(ts2 = tstamp_now();)
     meet_in_wave0<MB, NB>(acc, red, wave, lane);
     if (wave != 0) return;
+    MDM_TT(const unsigned long long ts3 = tstamp_now();
+           if (lane == 0 && blockIdx.x < 1024) { unsigned long long* r = g_tstamp_buf + blockIdx.x * 8; r[0] = 1; r[1] = ts1 - ts0; r[2] = ts2 - ts1; r[3] = ts3 - ts2; r[4] = ts0; r[5] = ts3; })
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int m = i * 16 + r16;
@@ -161,16 +187,21 @@ __global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict_
         for (int u = 0; u < DEPTH; ++u) {
             const int k = kb + 16 * u + kg;
             const bool live = kb + 16 * u < kbeg + kq;
+            const int kc = live ? k : kbeg + kg;    // (clamped addresses, values zeroed afterwards: see skinny_nt_kernel)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {          // W is [K][N]: 16 lanes read 64 contiguous bytes of each of 4 k-rows
                 const int n = n0 + j * 16 + r16;
-                const float* p = W + (int64_t)k * ldw + n;
-                b[u][j] = (live && n < N) ? make_float4(p[0], p[ldw], p[2 * (int64_t)ldw], p[3 * (int64_t)ldw]) : zero4;
+                const float* p = W + (int64_t)kc * ldw + (n < N ? n : N - 1);
+                const float w0 = p[0], w1 = p[ldw], w2 = p[2 * (int64_t)ldw], w3 = p[3 * (int64_t)ldw];
+                const bool ok = live && n < N;
+                b[u][j] = make_float4(ok ? w0 : 0.f, ok ? w1 : 0.f, ok ? w2 : 0.f, ok ? w3 : 0.f);
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const int m = i * 16 + r16;
-                a[u][i] = (live && m < M) ? *reinterpret_cast<const float4*>(dy + (int64_t)m * lddy + k) : zero4;
+                const float4 dv = *reinterpret_cast<const float4*>(dy + (int64_t)(m < M ? m : M - 1) * lddy + kc);
+                const bool ok = live && m < M;
+                a[u][i] = make_float4(ok ? dv.x : 0.f, ok ? dv.y : 0.f, ok ? dv.z : 0.f, ok ? dv.w : 0.f);
             }
         }
 #pragma unroll
@@ -263,3 +294,14 @@ extern "C" int mdm_silu_bwd_sum(const float* pre, const float* slabs, int nslab,
     hipLaunchKernelGGL(silu_bwd_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, slabs, nslab, n / 4, dx);
     return launch_status("silu_bwd_sum");
 }
+
+#ifdef MDM_STAMP
+extern "C" int mdm_debug_stamps_temb(unsigned long long* out, int reset) {      // out: 1024 * 8 entries
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mdm::g_tstamp_buf), 1024 * 8 * 8) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mdm::g_tstamp_buf)) != hipSuccess || hipMemset(p, 0, 1024 * 8 * 8) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
