@@ -549,10 +549,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
     const bool on = t < VB * PL && c < C;
     const int chunks = gridDim.z, chunk = blockIdx.z;
     const int plen = chunks == 1 ? P : (P + chunks - 1) / chunks, pbeg = chunk * plen, pend = min(P, pbeg + plen);
-    __shared__ float scratch[32 * CS_PITCH];
+    __shared__ float scratch[16 * CS_PITCH];
     __shared__ float csum[32 * 8];
-    __shared__ float gsum[2 * 64];
+    __shared__ float gsum[2 * 64], sgam[64];
     MDM_T(const unsigned long long ts0 = nstamp_now();)
+    if (t >= 128 && t < 128 + CBLK && cb + t - 128 < C) sgam[t - 128] = gamma[cb + t - 128];     // for the group sums behind the column sums
     if (t < 2 * ng) {
         float a = 0.f;
         if (MODE == 2)
@@ -569,10 +570,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
     // recomputed (exp + rcp per element: the large-map kernels are VALU-bound, 1 wave per SIMD)
     constexpr bool CACHE = MODE == 0 && NP <= 8;
     float gzc[CACHE ? NP : 1][8];
-    float ga[8], be[8], mean[8], rstd[8];
-    float part[32];
+    float ga[8], be[8], mean[8], rstd[8], nmr[8], za[8], zb[8];
+    float part[16];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) part[k] = 0.f;
+    for (int k = 0; k < 16; ++k) part[k] = 0.f;
     MDM_T(unsigned long long ts1 = 0;)
     if (on) {
 #pragma unroll
@@ -605,6 +606,15 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
             }
         }
         MDM_T(ts1 = nstamp_now();)
+        // (round 4: these kernels are VALU-bound -- ~60 vector instructions per element at two waves per SIMD, finding 48.  The
+        // normalisation and the affine map are one fma each from per-channel constants, and only TWO sums are kept per channel:
+        // sum(gz xh) = dgamma and sum(gz) = dbeta; the group sums of gz gamma and gz gamma xh are gamma-weighted sums of those
+        // two over the group's channels, taken once behind the column sums: 16 quantities through block_colsum instead of 32.)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            nmr[e] = -mean[e] * rstd[e];                     // xh = fma(x, rstd, nmr)
+            za[e] = rstd[e] * ga[e]; zb[e] = fmaf(nmr[e], ga[e], be[e]);      // gamma xh + beta = fma(x, za, zb)
+        }
         if (MODE != 2) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -614,30 +624,32 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
                 float dv[8] = F8_TO_ARR(d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float xh = (xv[e] - mean[e]) * rstd[e];
+                    float xh = fmaf(xv[e], rstd[e], nmr[e]);
                     float gz = dv[e];
-                    if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e]));
+                    if (silu) gz *= silu_grad_f(fmaf(xv[e], za[e], zb[e]));
                     if (CACHE) gzc[CACHE ? i : 0][e] = gz;
-                    part[16 + e] = fmaf(gz, xh, part[16 + e]); part[24 + e] += gz;          // dgamma, dbeta
-                    float gg = gz * ga[e];
-                    part[e] += gg; part[8 + e] = fmaf(gg, xh, part[8 + e]);                  // group sums
+                    part[e] = fmaf(gz, xh, part[e]); part[8 + e] += gz;                      // dgamma, dbeta
                 }
             }
         }
         }
     }
     if (MODE != 2) {
-        block_colsum<32, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {a1, a2, dgamma, dbeta}
+        block_colsum<16, NT>(part, scratch, csum, t, VB, PL);      // csum[(q*8+e)*VB + v], q = {dgamma, dbeta}
         if (t < CBLK && cb + t < C) {            // across images: one float atomic per (image, channel) (bf16 path)
             const int vv = t >> 3, e = t & 7;
-            atomicAdd(&dgamma[cb + t], csum[(16 + e) * VB + vv]);
-            atomicAdd(&dbeta[cb + t], csum[(24 + e) * VB + vv]);
+            atomicAdd(&dgamma[cb + t], csum[e * VB + vv]);
+            atomicAdd(&dbeta[cb + t], csum[(8 + e) * VB + vv]);
         }
         if (t >= 64 && t < 64 + ng) {            // inside the workgroup: fixed order (a second wave, next to the atomics above)
             const int gi = t - 64;
-            float gv[2];
-            group_sums<2>(csum, VB, gi * cpg, cpg, 8, gv);
-            gsum[2 * gi] += gv[0]; gsum[2 * gi + 1] += gv[1];
+            float a1 = 0.f, a2 = 0.f;            // sum over the group's channels of gamma dbeta / gamma dgamma, in channel order
+            for (int lc = gi * cpg; lc < (gi + 1) * cpg; ++lc) {
+                const float gm = sgam[lc];
+                a1 = fmaf(gm, csum[(8 + (lc & 7)) * VB + (lc >> 3)], a1);
+                a2 = fmaf(gm, csum[(lc & 7) * VB + (lc >> 3)], a2);
+            }
+            gsum[2 * gi] += a1; gsum[2 * gi + 1] += a2;
         }
     }
     MDM_T(const unsigned long long ts2 = nstamp_now();)
@@ -648,15 +660,16 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
         return;
     }
     MDM_T(const unsigned long long ts3 = nstamp_now(); const unsigned long long ts4 = ts3;)
-    float k1[8], k2[8], ag[8];
+    float k1[8], k2[8], ag[8];              // dx = ag gz - (k2 xh + k1) = fma(ag, gz, -fma(x, k2 rstd, k2 nmr + k1))
     if (on) {
         const float inv_cnt = 1.f / ((float)cpg * (float)P);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int gl = div_small(c + e, inv_cpg) - g0;
-            k1[e] = rstd[e] * gsum[2 * gl] * inv_cnt;
-            k2[e] = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
-            ag[e] = rstd[e] * ga[e];
+            const float q1 = rstd[e] * gsum[2 * gl] * inv_cnt, q2 = rstd[e] * gsum[2 * gl + 1] * inv_cnt;
+            k1[e] = fmaf(q2, nmr[e], q1);
+            k2[e] = q2 * rstd[e];
+            ag[e] = za[e];
         }
     }
     float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -674,11 +687,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_reg_kernel(const bf16_t* s0, int C0
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float xh = (xv[e] - mean[e]) * rstd[e];
                     float gz;
                     if (CACHE) gz = gzc[CACHE ? i : 0][e];
-                    else { gz = dv[e]; if (silu) gz *= silu_grad_f(fmaf(xh, ga[e], be[e])); }
-                    o[e] = ag[e] * gz - fmaf(xh, k2[e], k1[e]);
+                    else { gz = dv[e]; if (silu) gz *= silu_grad_f(fmaf(xv[e], za[e], zb[e])); }
+                    o[e] = fmaf(ag[e], gz, -fmaf(xv[e], k2[e], k1[e]));
                     sx[e] += o[e];
                 }
                 bf16_t* q = dst + (base + p) * CS + cc;
