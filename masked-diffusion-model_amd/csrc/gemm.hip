@@ -949,6 +949,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // select without a branch: p if ok else the zero page
 __device__ __forceinline__ const void* or_zero(bool ok, const void* p, const void* zero) { return ok ? p : zero; }
 
+#ifndef MDM_RING_PARITY
+#define MDM_RING_PARITY 1          // 0: stride-2 data gradients as plain nine-tap gathers (A/B builds)
+#endif
 template <int BM, int BN, int LAYOUT, int NSTAGE, bool CONV, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
     constexpr int BK = 64;
@@ -972,6 +975,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
     const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(d.B) + z.batch * d.sB;
     const bf16_t* S0 = reinterpret_cast<const bf16_t*>(d.src0);
     const bf16_t* S1 = reinterpret_cast<const bf16_t*>(d.src1);
+    // The data gradient of a stride-2 convolution (transposed gather): output pixel (oy, ox) takes tap (ty, tx) only where
+    // oy + pad_t - ty and ox + pad_l - tx are EVEN -- one, two, two or four of the nine taps, by the pixel's parity class.  As a plain
+    // gather three of four (pixel, tap) pairs read the zero page (12 + 25 + 25 us per step at cfg2 for a quarter of that work).
+    // `par`: the rows of the problem are taken in a PERMUTED order, class by class inside every image (class = the top two bits of the
+    // in-image index), so that a tile is one class, walks only that class's taps, and the epilogue stores row m at the pixel it stands for.
+    const int per_ = d.OH * d.OW;
+    const bool par = MDM_RING_PARITY && TAPMAJOR && d.transposed && d.stride == 2 && d.KH == 3 && d.KW == 3 && d.splitk <= 1 &&
+                     (per_ & (per_ - 1)) == 0 && (d.OW & (d.OW - 1)) == 0 && d.OW >= 2 && (per_ >> 2) % BM == 0 && d.M % BM == 0;
+    const int par_sp = par ? 31 - __clz(per_) : 2, par_c = par_sp - 2, par_h = par ? 30 - __clz(d.OW) : 0;   // log2: pixels, class size, OW / 2
+    auto par_pix = [&](int row, RowPix& rp) {                       // permuted row -> (image, oy, ox)
+        const int rem = row & (per_ - 1), cls = rem >> par_c, idx = rem & ((per_ >> 2) - 1);
+        rp.img = row >> par_sp;
+        rp.oy = 2 * (idx >> par_h) + (cls >> 1);
+        rp.ox = 2 * (idx & ((d.OW >> 1) - 1)) + (cls & 1);
+    };
+    const int par_cls = par ? ((m0 & (per_ - 1)) >> par_c) : 0;
+    // taps of this tile's class: ty in {ty0, ty0 + 2, ..} (ty = oy + pad_t mod 2), likewise tx
+    const int par_ty0 = ((par_cls >> 1) + d.pad_t) & 1, par_tx0 = ((par_cls & 1) + d.pad_l) & 1;
+    const int par_nty = par_ty0 ? 1 : 2, par_ntx = par_tx0 ? 1 : 2;
 
     // per-lane geometry of the pieces this wave fills (fixed for the whole k loop)
     const int r_sub = lane >> 3;                          // rows image: piece p covers rows 8p..8p+7
@@ -1002,6 +1024,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
             a_ok[j] = gm < d.M;
             if (TAPMAJOR) {
                 RowPix rp = decode_row(d, a_ok[j] ? gm : 0);
+                if (par) par_pix(a_ok[j] ? gm : 0, rp);
                 a_img[j] = rp.img; a_oy[j] = rp.oy; a_ox[j] = rp.ox;
             } else if (a_ok[j]) {
                 a_base[j] = reinterpret_cast<const char*>(Abase + (int64_t)gm * d.lda + 8 * r_lch);
@@ -1036,6 +1059,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
     const int tps = TAPMAJOR ? (d.KH * d.KW) / (d.splitk < 1 ? 1 : d.splitk) : 0;
     int seg_tap = TAPMAJOR ? z.ks * tps : 0, seg_src = 0, seg_c = 0;
     int tap_ty = TAPMAJOR ? seg_tap / d.KW : 0, tap_tx = TAPMAJOR ? seg_tap - (seg_tap / d.KW) * d.KW : 0;
+    if (par) { tap_ty = par_ty0; tap_tx = par_tx0; seg_tap = tap_ty * d.KW + tap_tx; }
     bool seg_dirty = true;
     int nxt_k = z.kbeg;
     const int nsrc = (TAPMAJOR && d.C1 > 0) ? 2 : 1;
@@ -1106,8 +1130,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
             if (seg_c >= (seg_src ? d.C1 : d.C0)) {                                                                   \
                 seg_c = 0; seg_dirty = true;                                                                          \
                 if (++seg_src == nsrc) {                                                                              \
-                    seg_src = 0; ++seg_tap;                                                                           \
-                    if (++tap_tx == d.KW) { tap_tx = 0; ++tap_ty; }                                                   \
+                    seg_src = 0;                                                                                      \
+                    if (par) {                 /* the next tap of this parity class */                               \
+                        tap_tx += 2;                                                                                  \
+                        if (tap_tx >= d.KW) { tap_tx = par_tx0; tap_ty += 2; }                                        \
+                        seg_tap = tap_ty * d.KW + tap_tx;                                                             \
+                    } else {                                                                                          \
+                        ++seg_tap;                                                                                    \
+                        if (++tap_tx == d.KW) { tap_tx = 0; ++tap_ty; }                                               \
+                    }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
         } else {                                                                                                      \
@@ -1130,7 +1161,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;      // bf16 1.0
 
-    const int nk = TAPMAJOR ? tps * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
+    const int nk = TAPMAJOR ? (par ? par_nty * par_ntx : tps) * (d.Ck / BK) : (z.kend - z.kbeg + BK - 1) / BK;
     // prologue: NSTAGE-1 slabs in flight.  Slabs past the end are issued too (all-zero or harmless
     // re-reads) so that the vmcnt bookkeeping below is the same for every trip count.
 #pragma unroll
@@ -1187,6 +1218,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_ring_kernel(mdm_gemm_desc d) {
     for (int i = 0; i < MI; ++i) {
         int m = m0 + wr * WM + i * 16 + (lane & 15);
         if (m >= d.M) continue;
+        if (par) { RowPix rp; par_pix(m, rp); m = (rp.img * d.OH + rp.oy) * d.OW + rp.ox; }      // the pixel this row stands for
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             int n = n0 + wc * WN + j * 16 + 4 * (lane >> 4);

@@ -55,6 +55,8 @@ CONV_CASES = [
     (2, 8, 64, 32, 48, 1, 1, (0, 0, 0, 0), 0),      # 1x1 skip conv over a concat
     (4, 16, 128, 0, 128, 3, 1, (1, 1, 1, 1), 0),    # big enough for several tiles
     (4, 16, 64, 0, 64, 3, 2, (0, 0, 1, 1), 0),      # stride 2 with a 64-aligned pixel count: linear-gather weight gradient
+    (8, 32, 64, 64, 128, 3, 2, (0, 0, 1, 1), 0),    # stride-2 data gradient in parity-class tiles (gemm_ring_kernel `par`): 64-row tiles, two destinations
+    (32, 32, 128, 0, 128, 3, 2, (0, 0, 1, 1), 0),   # ... 128-row tiles (the bench model's 16x16 -> 32x32 layer)
     (4, 8, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample, 16x16 virtual map: linear-gather weight gradient
     (32, 8, 64, 0, 128, 3, 1, (1, 1, 1, 1), 1),     # folded upsample, enough tiles for the halo kernel (forward)
     (8, 4, 64, 0, 64, 3, 1, (1, 1, 1, 1), 1),       # folded upsample onto an 8x8 map: whole-image halo tiles
